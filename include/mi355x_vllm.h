@@ -1,0 +1,172 @@
+/* mi355x_vllm.h — C ABI of libmi355x_vllm.so
+ *
+ * The inner drop-in boundary of the MI355X vLLM plugin: everything the reference
+ * (vllm-project/vllm-neuron @ 2025-11-21) obtains from the third-party NxDI model
+ * object is obtained from this library instead.  Plain pointers and sizes only, no
+ * torch / C++ types.  All calls arrive on ONE host thread (vLLM's "uni" executor,
+ * reference platform.py:120-121,166-167); a context is not thread-safe.
+ *
+ * Every function returns 0 on success and a negative MI_E* code on failure;
+ * mi_last_error() then describes the failure (the Python mirror raises it as
+ * RuntimeError / ValueError exactly where the reference raises).
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference):
+ *   mi_ctx_create      NxDI model-class ctor + neuron_config
+ *                      vllm_neuron/worker/neuronx_distributed_model_loader.py:216-218,236
+ *                      (fields: _get_default_neuron_config :725-793, overrides :870-900)
+ *   mi_load_weight     checkpoint load + save_quantized_state_dict      loader.py:234-241
+ *   mi_init_synthetic_weights   (bench only: no checkpoints exist offline)
+ *   mi_finalize        model.compile() + model.load()                    loader.py:240-241
+ *   mi_forward         NxDI model __call__ + logits[:, -1, :]            loader.py:339-363
+ *   mi_kv_stats        torch.classes.neuron.Runtime().get_vnc_memory_stats()
+ *                      vllm_neuron/worker/neuron_worker.py:51-63
+ *   mi_tp_*            NxDI tp_degree collectives                        loader.py:752-753
+ *   mi_op_*            (no reference counterpart: per-kernel entry points for the
+ *                      parity tests and micro-benchmarks; device pointers)
+ */
+#ifndef MI355X_VLLM_H
+#define MI355X_VLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define MI_EHIP (-2)     /* HIP runtime error (message has the string) */
+#define MI_ESTATE (-3)   /* call order violated (e.g. forward before finalize) */
+#define MI_ENOMEM (-4)
+#define MI_ECOMM (-5)    /* RCCL error */
+
+/* element types for host/device tensors crossing the ABI */
+enum { MI_F32 = 0, MI_BF16 = 1, MI_F8E4M3 = 2, MI_I8 = 3, MI_I64 = 4, MI_I32 = 5 };
+/* weight storage dtypes ("quantization_dtype", loader.py:895-896) */
+enum { MI_W_BF16 = 0, MI_W_F8E4M3 = 1, MI_W_INT8 = 2 };
+/* "quantization_type" (loader.py:892-894) */
+enum { MI_Q_PER_TENSOR_SYMMETRIC = 0, MI_Q_PER_CHANNEL_SYMMETRIC = 1 };
+enum { MI_ROPE_DEFAULT = 0, MI_ROPE_LLAMA3 = 1 };
+
+typedef struct mi_ctx mi_ctx;
+
+typedef struct mi_model_config {
+  /* decoder geometry (HF config; loader.py:612-631 derives nkv / head_dim the same way) */
+  int32_t num_layers, hidden_size, num_heads, num_kv_heads, head_dim;
+  int32_t intermediate_size, vocab_size;
+  float rms_norm_eps;
+  float rope_theta;
+  int32_t rope_type; /* MI_ROPE_* */
+  float rope_factor, rope_low_freq_factor, rope_high_freq_factor;
+  int32_t rope_original_max_position;
+  int32_t qkv_bias;            /* Qwen2 */
+  int32_t tie_word_embeddings; /* lm_head shares embed_tokens */
+  /* KV pool ("pa_num_blocks" incl. the null block 0, "pa_block_size": loader.py:741-745,775-778) */
+  int32_t num_blocks, block_size;
+  int32_t max_num_seqs;  /* "batch_size"  loader.py:738,756 */
+  int32_t max_model_len; /* "seq_len"     loader.py:760-761 */
+  /* "context_encoding_buckets" (README.md:80); 0 entries = one bucket of max_model_len */
+  int32_t num_ctx_buckets;
+  int32_t ctx_buckets[8];
+  /* quantization keys (loader.py:886-898) */
+  int32_t weight_dtype; /* MI_W_* ; MI_W_BF16 = not quantized */
+  int32_t quant_type;   /* MI_Q_* */
+  int32_t quantize_lm_head; /* 0 = "lm_head" listed in modules_to_not_convert */
+  /* tensor parallelism ("tp_degree" loader.py:752-753): one process per GPU */
+  int32_t tp_degree, tp_rank;
+  int32_t device_id;
+  int32_t use_graphs; /* capture token-generation steps into hipGraphs */
+} mi_model_config;
+
+const char* mi_last_error(void);
+int mi_version(void);
+
+int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out);
+int mi_ctx_destroy(mi_ctx* ctx);
+
+/* One HF-named tensor ("model.layers.3.self_attn.q_proj.weight", "lm_head.weight", ...),
+ * row-major on the host, dtype MI_F32 or MI_BF16, FULL (unsharded) shape.  The library
+ * slices its TP shard, quantizes (weight_dtype / quant_type) and re-tiles for the kernels. */
+int mi_load_weight(mi_ctx* ctx, const char* name, const void* host, int32_t dtype,
+                   const int64_t* shape, int32_t ndim);
+/* Bench/smoke only: N(0, std) matrices from a counter-based RNG in LOGICAL coordinates
+ * (identical values whatever the sharding); norm gains 1. */
+int mi_init_synthetic_weights(mi_ctx* ctx, uint64_t seed, float std);
+int mi_finalize(mi_ctx* ctx);
+
+/* One model call.  Host arrays, caller-owned, int64 like the reference's CPU tensors:
+ *   input_ids, position_ids [B, S]; seq_ids [B]; block_table [B, MB];
+ *   slot_mapping [B, SM]; full_context_lens, computed_context_lens [B];
+ *   logits_out [B, vocab_size] fp32 (last-token logits, loader.py:363).
+ * S == 1 -> token generation;  S > 1 -> context encoding of tokens
+ * computed..full-1 of each row (the FULL prompt is passed, runner.py:721-726,754).
+ * Slot -1 = no write; block-table entries past full_context_lens are never read. */
+int mi_forward(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_ids,
+               const int64_t* position_ids, const int64_t* seq_ids, const int64_t* block_table,
+               int32_t MB, const int64_t* slot_mapping, int32_t SM,
+               const int64_t* full_context_lens, const int64_t* computed_context_lens,
+               float* logits_out);
+
+typedef struct mi_kv_stats_t {
+  int64_t kv_bytes, weight_bytes, workspace_bytes, device_free_bytes, device_total_bytes;
+  int32_t num_blocks, block_size, num_kv_heads_local, head_dim, num_layers;
+} mi_kv_stats_t;
+int mi_kv_stats(mi_ctx* ctx, mi_kv_stats_t* out);
+
+/* hipStream_t the context launches on (for event timing by the caller). */
+void* mi_stream(mi_ctx* ctx);
+
+/* Per-kernel-class HIP-event timing of the following mi_forward calls (eager launches,
+ * no graph).  mi_profile_read returns, per class, launches and summed milliseconds. */
+enum { MI_K_GEMV = 0, MI_K_GEMM = 1, MI_K_ATTN_DECODE = 2, MI_K_ATTN_PREFILL = 3, MI_K_OTHER = 4,
+       MI_K_COMM = 5, MI_K_NUM = 6 };
+int mi_profile_enable(mi_ctx* ctx, int32_t on);
+int mi_profile_read(mi_ctx* ctx, int32_t* launches /*[MI_K_NUM]*/, float* ms /*[MI_K_NUM]*/,
+                    double* gemv_weight_bytes);
+
+/* Tensor parallel bring-up: rank 0 calls mi_tp_unique_id, the host layer broadcasts the
+ * 128 bytes, every rank calls mi_tp_init (ncclCommInitRank on the context's device). */
+int mi_tp_unique_id(void* out128);
+int mi_tp_init(mi_ctx* ctx, const void* id128);
+
+/* ---- per-kernel entry points (device pointers; stream may be NULL) -------------------- */
+
+/* Quantize + re-tile a row-major fp32 [N, K] device matrix.  scale_out [N] fp32.
+ * tiled_out: N*K bytes (fp8/int8) or 2*N*K (bf16), kernel-native 16-row tiles. */
+int mi_op_quantize_weight(const float* w, int32_t N, int32_t K, int32_t weight_dtype,
+                          int32_t quant_type, void* tiled_out, float* scale_out, void* stream);
+/* Inverse of the tiling for inspection: q_out row-major [N, K] (1 or 2 bytes/elem). */
+int mi_op_untile_weight(const void* tiled, int32_t N, int32_t K, int32_t weight_dtype,
+                        void* q_out, void* stream);
+/* y[M, N] fp32 = (x[M, K] bf16 . Wq^T) * scale (+ bias).  M <= 16: weight-streaming GEMV;
+ * else MFMA GEMM.  force_path: 0 auto, 1 GEMV, 2 GEMM. */
+int mi_op_qlinear(const void* x_bf16, int32_t M, const void* w_tiled, const float* scale,
+                  const float* bias, int32_t N, int32_t K, int32_t weight_dtype, float* y,
+                  int32_t force_path, void* stream);
+/* y[T, H] bf16 = rmsnorm(x[T, H] fp32) * g */
+int mi_op_rmsnorm(const float* x, const float* g, int32_t T, int32_t H, float eps, void* y_bf16,
+                  void* stream);
+/* Paged KV write.  k, v [T, nkv, hd] bf16; slots [T] (int64; -1 skips).
+ * pool layout (library-native): [2][num_blocks][nkv][block_size][hd] bf16. */
+int mi_op_kv_write(const void* k, const void* v, const int64_t* slots, int32_t T, int32_t nkv,
+                   int32_t hd, void* pool, int32_t num_blocks, int32_t block_size, void* stream);
+/* Token-generation attention.  q [B, nh, hd] bf16; block_table [B, MB] int32;
+ * ctx_lens [B] int32; out [B, nh*hd] bf16.  scratch: >= mi_op_attn_scratch_bytes. */
+int64_t mi_op_attn_scratch_bytes(int32_t B, int32_t nh, int32_t hd);
+int mi_op_paged_attn_decode(const void* q, const void* pool, int32_t num_blocks,
+                            int32_t block_size, const int32_t* block_table, int32_t MB,
+                            const int32_t* ctx_lens, int32_t B, int32_t nh, int32_t nkv,
+                            int32_t hd, void* out, void* scratch, void* stream);
+/* Context-encoding attention for ONE sequence.  q [T, nh, hd] bf16 are the new tokens at
+ * absolute positions q_pos0 .. q_pos0+T-1; keys 0 .. q_pos0+T-1 are read from the pool
+ * through block_table [MB] int32 (the new tokens' K/V must already be written). */
+int mi_op_paged_attn_prefill(const void* q, int32_t T, int32_t q_pos0, const void* pool,
+                             int32_t num_blocks, int32_t block_size, const int32_t* block_table,
+                             int32_t MB, int32_t nh, int32_t nkv, int32_t hd, void* out,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_VLLM_H */

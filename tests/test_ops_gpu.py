@@ -1,0 +1,194 @@
+"""Per-kernel parity on the MI355X, through the C ABI (mi_op_*), against the oracle / a plain
+torch fp32 reference of the same op."""
+
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle.quant import dequantize_weight, quantize_weight
+from tests.helpers import pool_to_native, ref_attention
+
+pytestmark = pytest.mark.gpu
+
+WD = {"bf16": 0, "f8e4m3": 1, "int8": 2}
+QT = {"per_tensor_symmetric": 0, "per_channel_symmetric": 1}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vllm_neuron_amd import _native
+    return _native
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def quantize_on_device(lib, w, wd, qt):
+    N, K = w.shape
+    wdev = dev(w.float().contiguous())
+    eb = 2 if wd == "bf16" else 1
+    tiled = torch.empty(N * K * eb, dtype=torch.uint8, device="cuda")
+    scale = torch.empty(N, dtype=torch.float32, device="cuda")
+    lib.check(lib.load_library().mi_op_quantize_weight(wdev.data_ptr(), N, K, WD[wd], QT[qt],
+                                                       tiled.data_ptr(), scale.data_ptr(), None))
+    torch.cuda.synchronize()
+    return tiled, scale
+
+
+@pytest.mark.parametrize("wd", ["f8e4m3", "int8", "bf16"])
+@pytest.mark.parametrize("qt", ["per_tensor_symmetric", "per_channel_symmetric"])
+def test_quantize_bit_exact(lib, wd, qt):
+    torch.manual_seed(0)
+    N, K = 80, 192
+    w = torch.randn(N, K) * 0.05
+    w[3] = 0.0                      # all-zero row -> scale 1
+    w[5, 7] = 3.0                   # outlier
+    w[6, :8] = torch.tensor([1e-4, -1e-4, 2e-3, -2e-3, 0.0117, 0.0118, -0.3, 0.3])
+    tiled, scale = quantize_on_device(lib, w, wd, qt)
+    eb = 2 if wd == "bf16" else 1
+    out = torch.empty(N * K * eb, dtype=torch.uint8, device="cuda")
+    lib.check(lib.load_library().mi_op_untile_weight(tiled.data_ptr(), N, K, WD[wd], out.data_ptr(), None))
+    torch.cuda.synchronize()
+    out = out.cpu()
+    if wd == "bf16":
+        got = out.view(torch.bfloat16).reshape(N, K)
+        assert torch.equal(got, w.to(torch.bfloat16))
+        return
+    q_ref, s_ref = quantize_weight(w, wd, qt)
+    assert torch.equal(scale.cpu(), s_ref)
+    got = out.view(torch.int8 if wd == "int8" else torch.float8_e4m3fn).reshape(N, K)
+    assert torch.equal(got.view(torch.uint8), q_ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("wd", ["f8e4m3", "int8", "bf16"])
+@pytest.mark.parametrize("M,path", [(1, 1), (4, 1), (16, 1), (4, 2), (17, 2), (200, 2), (256, 2)])
+@pytest.mark.parametrize("N,K", [(576, 448), (1024, 4096), (256, 14336)])
+def test_qlinear(lib, wd, M, path, N, K):
+    if M * K * 2 + 16384 > 160 * 1024 and path == 1:
+        pytest.skip("x does not fit LDS for the GEMV path")
+    torch.manual_seed(1)
+    w = torch.randn(N, K) * 0.05
+    x = torch.randn(M, K).to(torch.bfloat16)
+    bias = torch.randn(N) * 0.1
+    tiled, scale = quantize_on_device(lib, w, wd, "per_channel_symmetric")
+    if wd == "bf16":
+        wq = w.to(torch.bfloat16).float()
+    else:
+        wq = dequantize_weight(*quantize_weight(w, wd, "per_channel_symmetric"))
+    ref = x.float().double() @ wq.double().t() + bias.double()
+    y = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    xd, bd = dev(x), dev(bias)
+    lib.check(lib.load_library().mi_op_qlinear(xd.data_ptr(), M, tiled.data_ptr(), scale.data_ptr(), bd.data_ptr(),
+                                               N, K, WD[wd], y.data_ptr(), path, None))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    # fp32 accumulation of exact bf16 x {bf16,fp8,int8} products: only summation order differs
+    tol = 2e-5 * ref.abs().max().item() + 1e-5 * (K ** 0.5)
+    assert err < tol, (err, tol)
+
+
+def test_rmsnorm(lib):
+    torch.manual_seed(2)
+    T, H = 37, 448
+    x, g = torch.randn(T, H) * 3, 1 + 0.1 * torch.randn(H)
+    y = torch.empty(T, H, dtype=torch.bfloat16, device="cuda")
+    xd, gd = dev(x), dev(g)
+    lib.check(lib.load_library().mi_op_rmsnorm(xd.data_ptr(), gd.data_ptr(), T, H, 1e-5, y.data_ptr(), None))
+    torch.cuda.synchronize()
+    ref = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * g)
+    assert (y.cpu().float() - ref).abs().max() < 0.02
+    assert torch.equal(y.cpu(), ref.to(torch.bfloat16)) or (y.cpu().float() - ref).abs().max() < 0.017
+
+
+def _make_pool(nb, bs, nkv, hd, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = torch.randn(nb * bs, nkv, hd, generator=g).to(torch.bfloat16)
+    v = torch.randn(nb * bs, nkv, hd, generator=g).to(torch.bfloat16)
+    return k, v
+
+
+def test_kv_write(lib):
+    nb, bs, nkv, hd, T = 6, 32, 2, 64, 40
+    pool = torch.zeros(2, nb, nkv, bs, hd, dtype=torch.bfloat16, device="cuda")
+    k, v = _make_pool(2, 32, nkv, hd, 3)
+    k, v = k[:T], v[:T]
+    slots = torch.randperm((nb - 1) * bs)[:T] + bs          # never block 0
+    slots[5] = -1
+    kd, vd, sd = dev(k), dev(v), dev(slots.long())
+    lib.check(lib.load_library().mi_op_kv_write(kd.data_ptr(), vd.data_ptr(), sd.data_ptr(), T, nkv, hd,
+                                                pool.data_ptr(), nb, bs, None))
+    torch.cuda.synchronize()
+    p = pool.cpu()
+    ref = torch.zeros_like(p)
+    for t in range(T):
+        s = int(slots[t])
+        if s >= 0:
+            ref[0, s // bs, :, s % bs] = k[t]
+            ref[1, s // bs, :, s % bs] = v[t]
+    assert torch.equal(p, ref)
+
+
+@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 8, 1), (64, 7, 1), (128, 4, 4), (128, 2, 1)])
+@pytest.mark.parametrize("ctx", [[1, 31, 32, 33], [700, 5, 1024, 257], [2040]])
+def test_paged_attn_decode(lib, hd, nh, nkv, ctx):
+    bs, MB = 32, 64
+    B = len(ctx)
+    nb = 1 + B * MB
+    k, v = _make_pool(nb, bs, nkv, hd, 4)
+    pool = dev(pool_to_native(k, v, nb, bs))
+    perm = (torch.randperm(nb - 1, generator=torch.Generator().manual_seed(5)) + 1).tolist()
+    bt = torch.full((B, MB), -1, dtype=torch.int32)        # pad -1: must never be read
+    for b in range(B):
+        nblk = (ctx[b] + bs - 1) // bs
+        bt[b, :nblk] = torch.tensor(perm[b * MB:b * MB + nblk], dtype=torch.int32)
+    q = (torch.randn(B, nh, hd, generator=torch.Generator().manual_seed(6))).to(torch.bfloat16)
+    out = torch.empty(B, nh * hd, dtype=torch.bfloat16, device="cuda")
+    scratch = torch.empty(lib.load_library().mi_op_attn_scratch_bytes(B, nh, hd), dtype=torch.uint8, device="cuda")
+    qd, btd, cd = dev(q), dev(bt), dev(torch.tensor(ctx, dtype=torch.int32))
+    lib.check(lib.load_library().mi_op_paged_attn_decode(qd.data_ptr(), pool.data_ptr(), nb, bs, btd.data_ptr(), MB,
+                                                         cd.data_ptr(), B, nh, nkv, hd, out.data_ptr(),
+                                                         scratch.data_ptr(), None))
+    torch.cuda.synchronize()
+    kk, vv = k.float().reshape(nb, bs, nkv, hd), v.float().reshape(nb, bs, nkv, hd)
+    for b in range(B):
+        idx = torch.arange(ctx[b])
+        blk = bt[b, idx // bs].long()
+        K, V = kk[blk, idx % bs], vv[blk, idx % bs]
+        ref = ref_attention(q[b:b + 1].float(), K, V, torch.tensor([ctx[b] - 1]))
+        err = (out[b].cpu().float() - ref[0]).abs().max().item()
+        assert err < 0.02, (b, ctx[b], err)      # bf16 output rounding of O(1) values
+
+
+@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 8, 1), (64, 7, 1)])
+@pytest.mark.parametrize("T,pos0", [(6, 0), (79, 0), (70, 70), (9, 64), (300, 0), (130, 96)])
+def test_paged_attn_prefill(lib, hd, nh, nkv, T, pos0):
+    bs, MB = 32, 16
+    nb = 1 + MB
+    k, v = _make_pool(nb, bs, nkv, hd, 7)
+    pool = dev(pool_to_native(k, v, nb, bs))
+    perm = (torch.randperm(nb - 1, generator=torch.Generator().manual_seed(8)) + 1)
+    kv_len = pos0 + T
+    nblk = (kv_len + bs - 1) // bs
+    bt = torch.zeros(MB, dtype=torch.int32)
+    bt[:nblk] = perm[:nblk].int()
+    q = torch.randn(T, nh, hd, generator=torch.Generator().manual_seed(9)).to(torch.bfloat16)
+    out = torch.empty(T, nh * hd, dtype=torch.bfloat16, device="cuda")
+    qd, btd = dev(q), dev(bt)
+    lib.check(lib.load_library().mi_op_paged_attn_prefill(qd.data_ptr(), T, pos0, pool.data_ptr(), nb, bs,
+                                                          btd.data_ptr(), MB, nh, nkv, hd, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    idx = torch.arange(kv_len)
+    blk = bt[idx // bs].long()
+    kk, vv = k.float().reshape(nb, bs, nkv, hd), v.float().reshape(nb, bs, nkv, hd)
+    ref = ref_attention(q.float(), kk[blk, idx % bs], vv[blk, idx % bs], pos0 + torch.arange(T))
+    err = (out.cpu().float() - ref).abs().max().item()
+    assert err < 0.03, err     # P is rounded to bf16 before the P.V MFMA
+
+
+def test_errors_are_loud(lib):
+    L = lib.load_library()
+    with pytest.raises(ValueError):
+        lib.check(L.mi_op_qlinear(1, 4, 1, 1, None, 100, 64, 1, 1, 0, None))   # N % 16 != 0
+    assert b"N % 16" in L.mi_last_error()

@@ -1,0 +1,216 @@
+"""ctypes binding of libmi355x_vllm.so (include/mi355x_vllm.h).
+
+There is NO CPU fallback: importing this module without the built library, or
+creating a context without a HIP device, raises.  torch is imported first on
+purpose: the wheel bundles its own libamdhip64.so.7 / librccl.so.1 and the
+library's DT_NEEDED entries must resolve to those already-loaded copies so that
+the process holds ONE HIP runtime (torch device pointers are then valid here).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmi355x_vllm.so")
+
+MI_F32, MI_BF16 = 0, 1
+MI_W = {"bfloat16": 0, "bf16": 0, None: 0, "f8e4m3": 1, "fp8": 1, "int8": 2}
+MI_Q = {"per_tensor_symmetric": 0, "per_channel_symmetric": 1}
+K_CLASSES = ("gemv", "gemm", "attn_decode", "attn_prefill", "other", "comm")
+
+
+class MiModelConfig(C.Structure):
+    _fields_ = [
+        ("num_layers", C.c_int32), ("hidden_size", C.c_int32), ("num_heads", C.c_int32),
+        ("num_kv_heads", C.c_int32), ("head_dim", C.c_int32), ("intermediate_size", C.c_int32),
+        ("vocab_size", C.c_int32), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
+        ("rope_type", C.c_int32), ("rope_factor", C.c_float), ("rope_low_freq_factor", C.c_float),
+        ("rope_high_freq_factor", C.c_float), ("rope_original_max_position", C.c_int32),
+        ("qkv_bias", C.c_int32), ("tie_word_embeddings", C.c_int32),
+        ("num_blocks", C.c_int32), ("block_size", C.c_int32), ("max_num_seqs", C.c_int32),
+        ("max_model_len", C.c_int32), ("num_ctx_buckets", C.c_int32), ("ctx_buckets", C.c_int32 * 8),
+        ("weight_dtype", C.c_int32), ("quant_type", C.c_int32), ("quantize_lm_head", C.c_int32),
+        ("tp_degree", C.c_int32), ("tp_rank", C.c_int32), ("device_id", C.c_int32),
+        ("use_graphs", C.c_int32),
+    ]
+
+
+class MiKvStats(C.Structure):
+    _fields_ = [("kv_bytes", C.c_int64), ("weight_bytes", C.c_int64), ("workspace_bytes", C.c_int64),
+                ("device_free_bytes", C.c_int64), ("device_total_bytes", C.c_int64),
+                ("num_blocks", C.c_int32), ("block_size", C.c_int32),
+                ("num_kv_heads_local", C.c_int32), ("head_dim", C.c_int32), ("num_layers", C.c_int32)]
+
+
+_SIGS = {
+    "mi_last_error": (C.c_char_p, []),
+    "mi_version": (C.c_int, []),
+    "mi_ctx_create": (C.c_int, [C.POINTER(MiModelConfig), C.POINTER(C.c_void_p)]),
+    "mi_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "mi_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32,
+                                 C.POINTER(C.c_int64), C.c_int32]),
+    "mi_init_synthetic_weights": (C.c_int, [C.c_void_p, C.c_uint64, C.c_float]),
+    "mi_finalize": (C.c_int, [C.c_void_p]),
+    "mi_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                             C.c_void_p]),
+    "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
+    "mi_stream": (C.c_void_p, [C.c_void_p]),
+    "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                  C.POINTER(C.c_double)]),
+    "mi_tp_unique_id": (C.c_int, [C.c_void_p]),
+    "mi_tp_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_op_untile_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_void_p]),
+    "mi_op_qlinear": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_op_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                C.c_void_p]),
+    "mi_op_kv_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mi_op_attn_scratch_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "mi_op_paged_attn_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi_op_paged_attn_prefill": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().mi_last_error().decode("utf-8", "replace")
+        # -1 = MI_EINVAL: argument/shape errors surface as ValueError like the reference's config checks
+        if rc == -1:
+            raise ValueError(f"mi355x_vllm: {msg}")
+        raise NativeError(f"mi355x_vllm error {rc}: {msg}")
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class NativeModel:
+    """Owns one mi_ctx: device weights, paged KV pool, activations, stream."""
+
+    def __init__(self, **cfg):
+        self.lib = load_library()
+        c = MiModelConfig()
+        buckets = list(cfg.pop("ctx_buckets", None) or [])
+        for k, v in cfg.items():
+            if not hasattr(c, k):
+                raise ValueError(f"unknown native config field {k!r}")
+            setattr(c, k, v)
+        c.num_ctx_buckets = min(len(buckets), 8)
+        for i, b in enumerate(buckets[:8]):
+            c.ctx_buckets[i] = int(b)
+        self.cfg = c
+        self.vocab_size = c.vocab_size
+        self._ctx = C.c_void_p()
+        check(self.lib.mi_ctx_create(C.byref(c), C.byref(self._ctx)))
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.mi_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weight(self, name: str, tensor: "torch.Tensor") -> None:
+        t = tensor.detach().cpu().contiguous()
+        if t.dtype == torch.bfloat16:
+            dt = MI_BF16
+        else:
+            t, dt = t.to(torch.float32), MI_F32
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        check(self.lib.mi_load_weight(self._ctx, name.encode(), t.data_ptr(), dt, shape, t.dim()))
+
+    def load_state_dict(self, weights: dict) -> None:
+        for name, t in weights.items():
+            if t.dim() in (1, 2):
+                self.load_weight(name, t)
+
+    def init_synthetic_weights(self, seed: int = 1, std: float = 0.02) -> None:
+        check(self.lib.mi_init_synthetic_weights(self._ctx, seed, std))
+
+    def tp_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        check(self.lib.mi_tp_unique_id(buf))
+        return buf.raw
+
+    def tp_init(self, uid: bytes) -> None:
+        assert len(uid) == 128
+        check(self.lib.mi_tp_init(self._ctx, C.create_string_buffer(uid, 128)))
+
+    def finalize(self) -> None:
+        check(self.lib.mi_finalize(self._ctx))
+
+    def forward(self, input_ids, position_ids, seq_ids, block_table, slot_mapping,
+                full_context_lens, computed_context_lens) -> "torch.Tensor":
+        """CPU int64 tensors in (the reference's ModelInputForNeuron fields), fp32 CPU
+        last-token logits [B, V] out."""
+        def i64(t):
+            return t.to(torch.int64).contiguous()
+        ids, pos = i64(input_ids), i64(position_ids)
+        B, S = ids.shape
+        bt, sm = i64(block_table).reshape(B, -1), i64(slot_mapping).reshape(B, -1)
+        full, comp = i64(full_context_lens).reshape(-1), i64(computed_context_lens).reshape(-1)
+        seq = i64(seq_ids).reshape(-1) if seq_ids is not None else torch.zeros(B, dtype=torch.int64)
+        out = torch.empty(B, self.vocab_size, dtype=torch.float32)
+        check(self.lib.mi_forward(self._ctx, B, S, ids.data_ptr(), pos.data_ptr(), seq.data_ptr(),
+                                  bt.data_ptr(), bt.shape[1], sm.data_ptr(), sm.shape[1],
+                                  full.data_ptr(), comp.data_ptr(), out.data_ptr()))
+        return out
+
+    def kv_stats(self) -> dict:
+        s = MiKvStats()
+        check(self.lib.mi_kv_stats(self._ctx, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in MiKvStats._fields_}
+
+    def stream_handle(self) -> int:
+        return int(self.lib.mi_stream(self._ctx) or 0)
+
+    def profile_enable(self, on: bool) -> None:
+        check(self.lib.mi_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self) -> dict:
+        n = len(K_CLASSES)
+        launches, ms, wbytes = (C.c_int32 * n)(), (C.c_float * n)(), C.c_double()
+        check(self.lib.mi_profile_read(self._ctx, launches, ms, C.byref(wbytes)))
+        return {"launches": dict(zip(K_CLASSES, launches)), "ms": dict(zip(K_CLASSES, ms)),
+                "gemv_weight_bytes": wbytes.value}

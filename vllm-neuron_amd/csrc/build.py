@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Build libmi355x_vllm.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python vllm-neuron_amd/csrc/build.py [--force]
+
+Objects go to csrc/build/, the library next to the sources (in-tree, git-ignored: it
+travels to the GPU box with the snapshot).
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["linear_kernels.hip", "attn_kernels.hip", "misc_kernels.hip", "model.hip"]
+HEADERS = ["mi_common.h", "linear_kernels.h", "attn_kernels.h", "misc_kernels.h",
+           os.path.join("..", "..", "include", "mi355x_vllm.h")]
+LIB = os.path.join(HERE, "libmi355x_vllm.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-value", "-Wno-unused-result",
+         "-I/opt/rocm/include"]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src):
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+    if _mtime(obj) > max(_mtime(d) for d in deps) and "--force" not in sys.argv:
+        return obj, ""
+    cmd = ["hipcc", *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(verbose=True):
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    for _, warn in results:
+        if warn and verbose:
+            sys.stderr.write(warn)
+    if _mtime(LIB) < max(_mtime(o) for o in objs) or "--force" in sys.argv:
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB,
+               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build())

@@ -1,0 +1,569 @@
+// Weight-quantized linear layers for gfx950 (MI355X).
+//
+//   y[m, n] = (sum_k x[m, k] * q[n, k]) * scale[n] (+ bias[n])      q in {e4m3fn, int8, bf16}
+//
+// Replaces the NxDI quantized Column/RowParallel linears the reference reaches through
+// /root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py:339-348, with the
+// quantization keys of loader.py:886-898.
+//
+// Storage: the library owns the weights, so they are kept in the shape the matrix cores
+// want.  A tile is 16 output rows x 64 bytes of K (fp8/int8; 32 elements for bf16) = 1 KiB
+// laid out lane-linear: lane l holds the 16 bytes of row (l & 15), k-chunk (l >> 4).  One
+// 16-byte load per lane is then (a) a perfectly coalesced 1 KiB wave read and (b) exactly
+// the A operand of v_mfma_f32_16x16x32_bf16 after an in-register fp8->bf16 decode (two
+// k-steps per load for the 1-byte types).  Tiles of one 16-row group are contiguous along K,
+// so a wave streams a dense byte range.
+//
+// Decode (M <= 16): gemv_kernel — pure weight streaming, HBM-bound.  x lives in LDS in
+//   fragment order; every wave streams a K-slice of one row-tile with 2 x 8 KiB in flight;
+//   the MFMA does the dot products AND the cross-lane reduction; waves combine through LDS
+//   in a fixed order (deterministic, no atomics).
+// Prefill (M > 16): gemm_kernel — 128 x 128 tile, x through swizzled LDS, W straight
+//   from global in fragment order.
+//
+// Both share one epilogue on D[n = 4g + r][m = c] (lane = 16 g + c): dequant scale, bias,
+// then fp32 store | RoPE + q/KV-pool scatter | SwiGLU.
+
+#include "linear_kernels.h"
+
+namespace mi {
+
+// =====================================================================================
+// Epilogue
+// =====================================================================================
+template <int EPI>
+__device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_t v) {
+  const float4 sc = *reinterpret_cast<const float4*>(e.scale + n0);
+  v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+  if (e.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(e.bias + n0);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if constexpr (EPI == EPI_F32) {
+    *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ld_out + n0) =
+        make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_SWIGLU) {
+    const float a0 = v[0] / (1.f + __expf(-v[0])) * v[1];
+    const float a1 = v[2] / (1.f + __expf(-v[2])) * v[3];
+    *reinterpret_cast<uint32_t*>(e.act_out + (size_t)m * e.ld_act + (n0 >> 1)) =
+        pack_bf16x2(a0, a1);
+  } else {  // EPI_QKV
+    const int qk_end = e.q_dim + e.kv_dim;
+    if (n0 < qk_end) {  // rotary: (v0,v1) and (v2,v3) are (d, d + hd/2) pairs
+      const int j = (n0 < e.q_dim ? n0 : n0 - e.q_dim) % e.hd;
+      const int half = e.hd >> 1;
+      const float2 cs = *reinterpret_cast<const float2*>(e.rope_cos + (size_t)e.pos[m] * half + (j >> 1));
+      const float2 sn = *reinterpret_cast<const float2*>(e.rope_sin + (size_t)e.pos[m] * half + (j >> 1));
+      const float a0 = v[0] * cs.x - v[1] * sn.x, a1 = v[1] * cs.x + v[0] * sn.x;
+      const float b0 = v[2] * cs.y - v[3] * sn.y, b1 = v[3] * cs.y + v[2] * sn.y;
+      v[0] = a0; v[1] = a1; v[2] = b0; v[3] = b1;
+    }
+    const uint2 packed = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    if (n0 < e.q_dim) {
+      *reinterpret_cast<uint2*>(e.q_out + (size_t)m * e.q_dim + n0) = packed;
+    } else {
+      const int slot = e.slots[m];
+      if (slot >= 0) {
+        const bool is_k = n0 < qk_end;
+        const int rel = is_k ? n0 - e.q_dim : n0 - qk_end;
+        const int head = rel / e.hd, d = rel % e.hd;
+        const int blk = slot / e.block_size, off = slot % e.block_size;
+        uint16_t* pool = is_k ? e.kpool : e.vpool;
+        *reinterpret_cast<uint2*>(pool + (((size_t)blk * e.nkv + head) * e.block_size + off) * e.hd + d) = packed;
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// GEMV (token generation)
+// =====================================================================================
+// LDS: [x fragments: K/8 chunks * M * 16 B][red: 2 * WAVES * 64 lanes * 16 B]
+constexpr int kGemvWaves = 8;
+constexpr int kGemvU = 8;  // 1 KiB loads in flight per wave per batch (two batches live)
+
+size_t gemv_lds_bytes(int M, int K) {
+  return (size_t)M * K * 2 + 2 * kGemvWaves * 64 * 16;
+}
+bool gemv_fits(int M, int K) { return M <= 16 && gemv_lds_bytes(M, K) <= 160 * 1024; }
+
+// position (in 16-byte units) of the 8-element chunk c8 of row m in the fragment image
+template <int WD>
+__device__ __forceinline__ int xfrag_slot(int c8, int m, int M) {
+  if constexpr (WD == MI_W_BF16) {
+    return c8 * M + m;  // kt = c8 / 4, g = c8 % 4
+  } else {
+    const int kt = c8 >> 3, c = c8 & 7;  // k = kt*64 + g*16 + s*8 + j
+    return (((kt * 2 + (c & 1)) * 4 + (c >> 1)) * M) + m;
+  }
+}
+
+template <int WD, int PRO>
+__device__ __forceinline__ void gemv_stage_x(const ProArgs& p, int M, int K, uint4* xf, float* red_f) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int nchunk = K >> 3;
+  if constexpr (PRO == PRO_BF16) {
+    for (int i = tid; i < M * nchunk; i += nthr) {
+      const int m = i / nchunk, c8 = i - m * nchunk;
+      xf[xfrag_slot<WD>(c8, m, M)] =
+          *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+    }
+  } else {
+    // h = resid_in (+ partial); rmsnorm in fp32; x = bf16(h * rsqrt(mean h^2 + eps) * gain)
+    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    for (int m = 0; m < M; ++m) {
+      float ss = 0.f;
+      for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+        const float* hp = p.resid_in + (size_t)m * K + c8 * 8;
+        float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 4);
+        if (p.partial) {
+          const float* pp = p.partial + (size_t)m * K + c8 * 8;
+          const float4 pa = *reinterpret_cast<const float4*>(pp), pb = *reinterpret_cast<const float4*>(pp + 4);
+          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        }
+        ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red_f[m * 16 + wave] = ss;
+    }
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w) tot += red_f[m * 16 + w];
+      const float rinv = rsqrtf(tot / (float)K + p.eps);
+      for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+        const size_t o = (size_t)m * K + c8 * 8;
+        float4 a = *reinterpret_cast<const float4*>(p.resid_in + o), b = *reinterpret_cast<const float4*>(p.resid_in + o + 4);
+        if (p.partial) {
+          const float4 pa = *reinterpret_cast<const float4*>(p.partial + o), pb = *reinterpret_cast<const float4*>(p.partial + o + 4);
+          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+        }
+        if (p.resid_out && blockIdx.x == 0) {
+          *reinterpret_cast<float4*>(p.resid_out + o) = a;
+          *reinterpret_cast<float4*>(p.resid_out + o + 4) = b;
+        }
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gain + c8 * 8), g1 = *reinterpret_cast<const float4*>(p.gain + c8 * 8 + 4);
+        uint4 o4;
+        o4.x = pack_bf16x2(a.x * rinv * g0.x, a.y * rinv * g0.y);
+        o4.y = pack_bf16x2(a.z * rinv * g0.z, a.w * rinv * g0.w);
+        o4.z = pack_bf16x2(b.x * rinv * g1.x, b.y * rinv * g1.y);
+        o4.w = pack_bf16x2(b.z * rinv * g1.z, b.w * rinv * g1.w);
+        xf[xfrag_slot<WD>(c8, m, M)] = o4;
+      }
+    }
+  }
+}
+
+template <int WD, int PRO, int EPI>
+__global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __restrict__ W, int NT, int KT,
+                                                               int M, int K, ProArgs p, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* xf = reinterpret_cast<uint4*>(smem);
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  // this wave's K-slice (in tiles), identical for every row-tile
+  const int ktw = ceil_div(KT, kGemvWaves);
+  const int kbeg = min(wave * ktw, KT), kend = min(kbeg + ktw, KT);
+  const int nb = max(1, ceil_div(ktw, kGemvU));  // batches per row-tile: SAME for every wave (barriers)
+  const int my_tiles = blockIdx.x < NT ? ceil_div(NT - blockIdx.x, gridDim.x) : 0;
+  const int total = my_tiles * nb;
+
+  uint4 bufA[kGemvU], bufB[kGemvU];
+  auto issue = [&](uint4 (&buf)[kGemvU], int i) {
+    const int tile = blockIdx.x + (i / nb) * gridDim.x;
+    const int kt0 = kbeg + (i % nb) * kGemvU;
+    const uint4* base = W + ((size_t)tile * KT + kt0) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u)
+      if (kt0 + u < kend) buf[u] = nt_load16(base + (size_t)u * 64);
+  };
+
+  if (total > 0) issue(bufA, 0);          // weights start moving before x is staged
+  gemv_stage_x<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
+  __syncthreads();
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int parity = 0;
+  auto process = [&](uint4 (&buf)[kGemvU], int i) {
+    const int kt0 = kbeg + (i % nb) * kGemvU;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) {
+      const int kt = kt0 + u;
+      if (kt < kend) {
+        if constexpr (WD == MI_W_BF16) {
+          bf16x8_t b = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (c < M) b = __builtin_bit_cast(bf16x8_t, xf[(kt * 4 + g) * M + c]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[u]), b, acc, 0, 0, 0);
+        } else {
+          bf16x8_t b0 = {0, 0, 0, 0, 0, 0, 0, 0}, b1 = b0;
+          if (c < M) {
+            b0 = __builtin_bit_cast(bf16x8_t, xf[((kt * 2 + 0) * 4 + g) * M + c]);
+            b1 = __builtin_bit_cast(bf16x8_t, xf[((kt * 2 + 1) * 4 + g) * M + c]);
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(buf[u].x, buf[u].y), b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(buf[u].z, buf[u].w), b1, acc, 0, 0, 0);
+        }
+      }
+    }
+    if ((i % nb) == nb - 1) {  // row-tile finished: combine the K-slices in wave order
+      const int seq = i / nb;
+      const int tile = blockIdx.x + seq * gridDim.x;
+      red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == (seq % kGemvWaves)) {
+        f32x4_t s = red[(parity * kGemvWaves) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kGemvWaves; ++w) {
+          const f32x4_t t = red[(parity * kGemvWaves + w) * 64 + lane];
+          s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        if (c < M) epilogue<EPI>(e, c, tile * 16 + g * 4, s);
+      }
+      parity ^= 1;
+      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  for (int i = 0; i < total; i += 2) {
+    if (i + 1 < total) issue(bufB, i + 1);
+    process(bufA, i);
+    if (i + 1 < total) {
+      if (i + 2 < total) issue(bufA, i + 2);
+      process(bufB, i + 1);
+    }
+  }
+}
+
+template <int WD, int PRO, int EPI>
+static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  const int NT = w.N / 16, KT = w.K / tile_k(WD);
+  const size_t lds = gemv_lds_bytes(M, w.K);
+  auto kern = gemv_kernel<WD, PRO, EPI>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+  const int grid = min(NT, 256 * wg_per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s,
+                     reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K, p, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+template <int WD>
+static int launch_gemv_wd(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
+  if (pro == PRO_NORM) {
+    if (epi == EPI_QKV) return launch_gemv_t<WD, PRO_NORM, EPI_QKV>(w, M, p, e, s);
+    if (epi == EPI_SWIGLU) return launch_gemv_t<WD, PRO_NORM, EPI_SWIGLU>(w, M, p, e, s);
+    return launch_gemv_t<WD, PRO_NORM, EPI_F32>(w, M, p, e, s);
+  }
+  if (epi == EPI_QKV) return launch_gemv_t<WD, PRO_BF16, EPI_QKV>(w, M, p, e, s);
+  if (epi == EPI_SWIGLU) return launch_gemv_t<WD, PRO_BF16, EPI_SWIGLU>(w, M, p, e, s);
+  return launch_gemv_t<WD, PRO_BF16, EPI_F32>(w, M, p, e, s);
+}
+
+int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
+  MI_CHECK(M >= 1 && M <= 16, "gemv: M must be 1..16");
+  MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemv: N % 16 == 0 and K % 64 == 0 required");
+  MI_CHECK(gemv_fits(M, w.K), "gemv: x does not fit in LDS");
+  switch (w.wd) {
+    case MI_W_BF16: return launch_gemv_wd<MI_W_BF16>(w, M, pro, p, epi, e, s);
+    case MI_W_F8E4M3: return launch_gemv_wd<MI_W_F8E4M3>(w, M, pro, p, epi, e, s);
+    case MI_W_INT8: return launch_gemv_wd<MI_W_INT8>(w, M, pro, p, epi, e, s);
+  }
+  set_error("gemv: bad weight dtype");
+  return MI_EINVAL;
+}
+
+// =====================================================================================
+// GEMM (context encoding)
+// =====================================================================================
+// Work-group tile 128 (n) x 128 (m); 4 waves as 2 (n) x 2 (m), each 64 x 64 = 4 x 4 MFMA tiles.
+// x tile [128 m][64 k] bf16 through LDS (16-byte chunks XOR-swizzled by row); W fragments
+// straight from the pre-tiled global image.
+constexpr int kBM = 128, kBN = 128, kBK = 64;
+
+template <int WD, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
+                                                   const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) uint4 xs[kBM * 8];  // 16 KiB
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int m0 = blockIdx.x * kBM, nt0 = blockIdx.y * (kBN / 16) + wn * 4;
+  const int nks = K / kBK;
+  constexpr int WPK = (WD == MI_W_BF16) ? 2 : 1;  // weight tiles per K-step
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // x staging: thread -> rows (tid/8 + 32 i), 16-byte chunk tid%8
+  const int srow = tid >> 3, sch = tid & 7;
+  uint4 xr[4];
+  uint4 wr[4][WPK], wnx[4][WPK];
+  auto load_x = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + srow + 32 * i;
+      xr[i] = (m < T) ? *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + ks * kBK + sch * 8)
+                      : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto load_w = [&](uint4 (&dst)[4][WPK], int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < WPK; ++t)
+        dst[i][t] = (nt0 + i < NT) ? W[((size_t)(nt0 + i) * KT + ks * WPK + t) * 64 + lane] : make_uint4(0, 0, 0, 0);
+  };
+
+  load_x(0);
+  load_w(wr, 0);
+  for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = srow + 32 * i;
+      xs[r * 8 + (sch ^ (r & 7))] = xr[i];
+    }
+    __syncthreads();
+    if (ks + 1 < nks) {
+      load_x(ks + 1);
+      load_w(wnx, ks + 1);
+    }
+    bf16x8_t bfr[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r = wm * 64 + mt * 16 + c;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ch = (WD == MI_W_BF16) ? (4 * s + g) : (2 * g + s);
+        bfr[mt][s] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch ^ (r & 7))]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8_t a0, a1;
+      if constexpr (WD == MI_W_BF16) {
+        a0 = __builtin_bit_cast(bf16x8_t, wr[i][0]);
+        a1 = __builtin_bit_cast(bf16x8_t, wr[i][1]);
+      } else {
+        a0 = decode8<WD>(wr[i][0].x, wr[i][0].y);
+        a1 = decode8<WD>(wr[i][0].z, wr[i][0].w);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[mt][0], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[mt][1], acc[i][mt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (ks + 1 < nks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < WPK; ++t) wr[i][t] = wnx[i][t];
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (nt0 + i >= NT) continue;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + c;
+      if (m < T) epilogue<EPI>(e, m, (nt0 + i) * 16 + g * 4, acc[i][mt]);
+    }
+  }
+}
+
+template <int WD>
+static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  const int NT = w.N / 16, KT = w.K / tile_k(WD);
+  dim3 grid(ceil_div(T, kBM), ceil_div(w.N, kBN));
+  const uint4* W = reinterpret_cast<const uint4*>(w.w);
+  if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_kernel<WD, EPI_QKV>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
+  else if (epi == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<WD, EPI_SWIGLU>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
+  else hipLaunchKernelGGL((gemm_kernel<WD, EPI_F32>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  MI_CHECK(T >= 1, "gemm: T must be >= 1");
+  MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemm: N % 16 == 0 and K % 64 == 0 required");
+  MI_CHECK(ldx % 8 == 0, "gemm: x row stride must be a multiple of 8 elements");
+  switch (w.wd) {
+    case MI_W_BF16: return launch_gemm_wd<MI_W_BF16>(w, T, x, ldx, epi, e, s);
+    case MI_W_F8E4M3: return launch_gemm_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s);
+    case MI_W_INT8: return launch_gemm_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s);
+  }
+  set_error("gemm: bad weight dtype");
+  return MI_EINVAL;
+}
+
+// =====================================================================================
+// Load-time quantize + tile
+// =====================================================================================
+__global__ void rowmax_kernel(const float* __restrict__ w, int ld, float* __restrict__ rowmax) {
+  const float* r = w + (size_t)blockIdx.x * ld;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < ld; i += blockDim.x) m = fmaxf(m, fabsf(r[i]));
+  __shared__ float sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowmax[blockIdx.x] = sm[0];
+}
+__global__ void allmax_kernel(const float* __restrict__ rowmax, int n, float* __restrict__ out) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, rowmax[i]);
+  __shared__ float sm[256];
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+// fp32 -> OCP e4m3fn, round-nearest-even, |f| <= 448 (software: bit-exact by construction)
+__device__ __forceinline__ uint32_t f32_to_e4m3fn(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  const float a = fabsf(f);
+  uint32_t code;
+  if (!(a < 448.f)) {
+    code = 0x7Eu;
+  } else if (a < 0.015625f) {            // below the smallest normal 2^-6: step 2^-9
+    code = (uint32_t)rintf(a * 512.f);    // 8 rounds up into the first normal, encoding is continuous
+  } else {
+    const uint32_t ub = u & 0x7fffffffu;
+    const uint32_t r = ub + 0x7FFFFu + ((ub >> 20) & 1u);
+    code = ((((r >> 23) - 127u + 7u) << 3) | ((r >> 20) & 7u));
+    code = code > 0x7Eu ? 0x7Eu : code;
+  }
+  return sign | code;
+}
+
+__device__ __forceinline__ int dst_to_src_row(const QuantJob& j, int r) {
+  const int rel = r - j.dst_row0;
+  if (rel < 0) return -1;
+  int i;
+  if (j.rowmap == ROWMAP_PLAIN) {
+    i = rel;
+  } else if (j.rowmap == ROWMAP_ROPE_PAIRS) {
+    const int head = rel / j.hd, jj = rel % j.hd;
+    i = head * j.hd + ((jj & 1) ? (jj >> 1) + (j.hd >> 1) : (jj >> 1));
+  } else {
+    if (rel & 1) return -1;
+    i = rel >> 1;
+  }
+  return i < j.n_rows ? i : -1;
+}
+
+// one wave per destination tile
+template <int WD>
+__global__ __launch_bounds__(256) void quant_tile_kernel(QuantJob j, int nt_lo, int nt_cnt, int KT) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= nt_cnt * KT) return;
+  const int nt = nt_lo + wave / KT, kt = wave % KT;
+  const int r = nt * 16 + (lane & 15), gq = lane >> 4;
+  const int i = dst_to_src_row(j, r);
+  if (i < 0) return;
+  const int srow = j.src_row0 + i;
+  constexpr int EPL = (WD == MI_W_BF16) ? 8 : 16;  // elements per lane
+  const float* src = j.src + (size_t)srow * j.ld + j.src_col0 + kt * (EPL * 4) + gq * EPL;
+  float scale = 1.f;
+  if constexpr (WD != MI_W_BF16) {
+    const float qmax = (WD == MI_W_INT8) ? 127.f : 448.f;
+    const float amax = (j.quant_type == MI_Q_PER_TENSOR_SYMMETRIC) ? j.tmp_rowmax[j.src_rows_total] : j.tmp_rowmax[srow];
+    scale = amax > 0.f ? amax / qmax : 1.f;
+  }
+  if (kt == 0 && gq == 0) j.dst_scale[r] = scale;
+  uint4 out;
+  if constexpr (WD == MI_W_BF16) {
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(src[2 * k], src[2 * k + 1]);
+    out = make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+    const float qmax = (WD == MI_W_INT8) ? 127.f : 448.f;
+    uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float t = src[k] / scale;
+      t = fminf(fmaxf(t, -qmax), qmax);
+      uint32_t b;
+      if constexpr (WD == MI_W_INT8) b = (uint32_t)(int)rintf(t) & 0xffu;
+      else b = f32_to_e4m3fn(t);
+      o[k >> 2] |= b << (8 * (k & 3));
+    }
+    out = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+  reinterpret_cast<uint4*>(j.dst)[((size_t)nt * KT + kt) * 64 + lane] = out;
+}
+
+int run_quant_job(const QuantJob& j, hipStream_t s) {
+  MI_CHECK(j.K % 64 == 0, "quantize: K % 64 == 0 required");
+  if (j.wd != MI_W_BF16) {
+    hipLaunchKernelGGL(rowmax_kernel, dim3(j.src_rows_total), dim3(256), 0, s, j.src, j.ld, j.tmp_rowmax);
+    hipLaunchKernelGGL(allmax_kernel, dim3(1), dim3(256), 0, s, j.tmp_rowmax, j.src_rows_total, j.tmp_rowmax + j.src_rows_total);
+  }
+  // destination rows touched: [dst_row0, dst_row0 + span)
+  const int span = (j.rowmap == ROWMAP_EVERY_OTHER) ? 2 * j.n_rows : j.n_rows;
+  const int nt_lo = j.dst_row0 / 16, nt_hi = ceil_div(j.dst_row0 + span, 16);
+  const int KT = j.K / tile_k(j.wd);
+  const int waves = (nt_hi - nt_lo) * KT;
+  const dim3 grid(ceil_div(waves, 4)), block(256);
+  if (j.wd == MI_W_BF16) hipLaunchKernelGGL((quant_tile_kernel<MI_W_BF16>), grid, block, 0, s, j, nt_lo, nt_hi - nt_lo, KT);
+  else if (j.wd == MI_W_F8E4M3) hipLaunchKernelGGL((quant_tile_kernel<MI_W_F8E4M3>), grid, block, 0, s, j, nt_lo, nt_hi - nt_lo, KT);
+  else hipLaunchKernelGGL((quant_tile_kernel<MI_W_INT8>), grid, block, 0, s, j, nt_lo, nt_hi - nt_lo, KT);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// tiled -> row-major (inspection / tests)
+__global__ void untile_kernel(const uint4* __restrict__ tiled, int NT, int KT, int K, int eb, unsigned char* __restrict__ out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= NT * KT) return;
+  const int nt = wave / KT, kt = wave % KT;
+  const uint4 v = tiled[(size_t)wave * 64 + lane];
+  const int r = nt * 16 + (lane & 15);
+  // 16 bytes = 16 elements (1-byte types) or 8 elements (bf16)
+  const size_t byte_col = (size_t)kt * 64 + (lane >> 4) * 16;
+  *reinterpret_cast<uint4*>(out + (size_t)r * K * eb + byte_col) = v;
+}
+
+int launch_untile(const void* tiled, int N, int K, int wd, void* out, hipStream_t s) {
+  MI_CHECK(N % 16 == 0 && K % 64 == 0, "untile: N % 16 == 0 and K % 64 == 0 required");
+  const int NT = N / 16, KT = K / tile_k(wd);
+  hipLaunchKernelGGL(untile_kernel, dim3(ceil_div(NT * KT, 4)), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(tiled), NT, KT, K, elem_bytes(wd), reinterpret_cast<unsigned char*>(out));
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = bf16_to_f32(in[i]);
+}
+int launch_bf16_to_f32(const uint16_t* in, float* out, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(2048), dim3(256), 0, s, in, out, n);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+}  // namespace mi

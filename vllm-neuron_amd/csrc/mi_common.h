@@ -1,0 +1,126 @@
+// Shared device/host helpers for libmi355x_vllm (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/mi355x_vllm.h"
+
+namespace mi {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA 16x16x32 operand
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+constexpr int kWave = 64;
+
+// ---- error plumbing -------------------------------------------------------------------
+void set_error(const std::string& msg);
+#define MI_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      mi::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));               \
+      return MI_EHIP;                                                                 \
+    }                                                                                 \
+  } while (0)
+#define MI_CHECK(cond, msg)                                                           \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      mi::set_error(std::string(msg) + " [" #cond "]");                               \
+      return MI_EINVAL;                                                               \
+    }                                                                                 \
+  } while (0)
+
+// ---- scalar conversions ---------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+  return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) {
+  return __builtin_bit_cast(float, packed << 16);
+}
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) {
+  return __builtin_bit_cast(float, packed & 0xffff0000u);
+}
+// round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// ---- weight-fragment decode: 8 stored weights -> 8 bf16 (one MFMA operand) --------------
+// fp8 e4m3fn and int8 values are exactly representable in bf16.
+template <int WD>
+__device__ __forceinline__ bf16x8_t decode8(uint32_t lo, uint32_t hi);
+
+template <>
+__device__ __forceinline__ bf16x8_t decode8<MI_W_F8E4M3>(uint32_t lo, uint32_t hi) {
+  union { bf16x2_t p[4]; bf16x8_t v; } u;
+  u.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false);
+  u.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  u.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false);
+  u.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return u.v;
+}
+
+__device__ __forceinline__ uint32_t i8x2_to_bf16x2(uint32_t w, int byte0, int byte1) {
+  float a = (float)(int)(int8_t)(w >> (8 * byte0));
+  float b = (float)(int)(int8_t)(w >> (8 * byte1));
+  return pack_bf16x2(a, b);
+}
+template <>
+__device__ __forceinline__ bf16x8_t decode8<MI_W_INT8>(uint32_t lo, uint32_t hi) {
+  union { uint32_t p[4]; bf16x8_t v; } u;
+  u.p[0] = i8x2_to_bf16x2(lo, 0, 1);
+  u.p[1] = i8x2_to_bf16x2(lo, 2, 3);
+  u.p[2] = i8x2_to_bf16x2(hi, 0, 1);
+  u.p[3] = i8x2_to_bf16x2(hi, 2, 3);
+  return u.v;
+}
+
+// ---- cross-lane sums inside an aligned group of 8 or 16 lanes (DPP, no LDS) ------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  float t = __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+  return v + t;
+}
+// after the call every lane of the group holds the group's sum
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LANES == 8 || LANES == 16, "group of 8 or 16 lanes");
+  if (LANES == 16) v = dpp_add<0x140>(v);  // row_mirror       i <-> 15-i
+  v = dpp_add<0x141>(v);                   // row_half_mirror  i <-> 7-i (within 8)
+  v = dpp_add<0xB1>(v);                    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                    // quad_perm [2,3,0,1]
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group_sum<16>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// streamed-once 16-byte load (global_load_dwordx4 ... nt): keeps weight bytes out of the way
+// of the L2 lines that ARE reused (activations, scales)
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+__host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// weight tile geometry: a tile is 16 rows x TILE_K(wd) columns = 1 KiB, lane l owns
+// row (l & 15), k-chunk (l >> 4) of 16 bytes.
+__host__ __device__ __forceinline__ int tile_k(int wd) { return wd == MI_W_BF16 ? 32 : 64; }
+__host__ __device__ __forceinline__ int elem_bytes(int wd) { return wd == MI_W_BF16 ? 2 : 1; }
+
+}  // namespace mi

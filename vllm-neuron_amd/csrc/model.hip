@@ -1,0 +1,884 @@
+// libmi355x_vllm: context, weight loading and the model call behind include/mi355x_vllm.h.
+//
+// mi_forward is the MI355X counterpart of the NxDI model __call__ that the reference reaches
+// at /root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py:339-348 and of the
+// logits[:, -1, :] slice at :363.  One host thread, one HIP stream, library-owned device
+// memory (weights, paged KV pool, activations), caller-owned host arrays.
+//
+// Per decoder layer (token generation, 6 launches, captured in a hipGraph per batch size):
+//   gemv[norm -> QKV -> bias -> RoPE -> q buffer + KV-pool scatter]
+//   paged attention (split) ; combine
+//   gemv[O proj -> fp32 partial]                     (+ RCCL all-reduce when tp_degree > 1)
+//   gemv[residual add + norm -> gate|up -> SwiGLU]
+//   gemv[down proj -> fp32 partial]                  (+ RCCL all-reduce)
+// The residual stream is fp32 and ping-pongs between two buffers: the norm prologue of the
+// NEXT kernel folds in the previous partial, so a row-parallel output needs no extra pass.
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attn_kernels.h"
+#include "linear_kernels.h"
+#include "misc_kernels.h"
+
+namespace mi {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace mi
+
+using namespace mi;
+
+#define MI_TRY(expr)             \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != MI_OK) return _rc; \
+  } while (0)
+
+namespace {
+
+struct Linear {
+  void* w = nullptr;
+  float* scale = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0, wd = MI_W_BF16;
+  LinearW view() const { return LinearW{w, N, K, wd}; }
+  size_t bytes() const { return (size_t)N * K * elem_bytes(wd); }
+};
+
+struct LayerW {
+  Linear qkv, o, gu, down;
+  float* g_in = nullptr;
+  float* g_post = nullptr;
+};
+
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> cls;
+  int launches[MI_K_NUM] = {0};
+  float ms[MI_K_NUM] = {0};
+  double gemv_bytes = 0;
+};
+
+}  // namespace
+
+struct mi_ctx {
+  mi_model_config cfg;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+  // per-rank geometry
+  int H = 0, hd = 0, nh_l = 0, nkv_l = 0, kvh0 = 0, q_dim = 0, kv_dim = 0, I_l = 0, V_l = 0, max_rows = 0;
+  std::vector<LayerW> layers;
+  uint16_t* embed = nullptr;
+  Linear lm_head;
+  float* g_final = nullptr;
+  bool have_lm_head = false;
+  // KV pool: [L][2][NB][nkv_l][bs][hd] bf16
+  uint16_t* kv_pool = nullptr;
+  size_t kv_half = 0;  // elements of one K (or V) pool of one layer
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  // weight-load staging
+  void* stage_raw = nullptr;
+  float* stage_f32 = nullptr;
+  float* rowmax = nullptr;
+  size_t stage_elems = 0;
+  // activations
+  float* resid[2] = {nullptr, nullptr};
+  float* partial = nullptr;
+  uint16_t *xn = nullptr, *qbuf = nullptr, *attn_out = nullptr, *act = nullptr;
+  float* logits = nullptr;      // [max_num_seqs, V_l]
+  float* logits_all = nullptr;  // [tp, max_num_seqs, V_l] (tp > 1)
+  void* attn_scratch = nullptr;
+  // step inputs
+  int32_t *d_ids = nullptr, *d_pos = nullptr, *d_slots = nullptr, *d_bt = nullptr, *d_ctx = nullptr;
+  int32_t *h_ids = nullptr, *h_pos = nullptr, *h_slots = nullptr, *h_bt = nullptr, *h_ctx = nullptr;
+  float* h_logits = nullptr;
+  int MB_cap = 0;
+  size_t weight_bytes = 0, workspace_bytes = 0, kv_bytes = 0;
+  std::map<int, hipGraphExec_t> graphs;  // token-generation graph per (B * 65536 + MB)
+  Prof prof;
+  ncclComm_t comm = nullptr;
+};
+
+namespace {
+
+// ---- memory helpers ---------------------------------------------------------------------
+template <typename T>
+int dmalloc(T** p, size_t n, size_t* tally = nullptr) {
+  MI_HIP(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  if (tally) *tally += n * sizeof(T);
+  return MI_OK;
+}
+
+int alloc_linear(mi_ctx* c, Linear& L, int N, int K, int wd, bool bias) {
+  L.N = N; L.K = K; L.wd = wd;
+  MI_CHECK(N % 16 == 0 && K % 64 == 0, "linear dims: N % 16 == 0 and K % 64 == 0 required (per TP shard)");
+  MI_HIP(hipMalloc(&L.w, L.bytes()));
+  c->weight_bytes += L.bytes();
+  MI_TRY(dmalloc(&L.scale, (size_t)N, &c->weight_bytes));
+  if (bias) {
+    MI_TRY(dmalloc(&L.bias, (size_t)N, &c->weight_bytes));
+    MI_HIP(hipMemsetAsync(L.bias, 0, (size_t)N * 4, c->stream));
+  }
+  return MI_OK;
+}
+
+// ---- profiling wrapper ---------------------------------------------------------------------
+struct Scope {
+  mi_ctx* c;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  Scope(mi_ctx* c_, int cls_) : c(c_), cls(cls_) {
+    if (c->prof.on) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~Scope() {
+    if (c->prof.on) {
+      hipEventRecord(b, c->stream);
+      c->prof.ev.push_back(a);
+      c->prof.ev.push_back(b);
+      c->prof.cls.push_back(cls);
+    }
+  }
+};
+
+int prof_collect(mi_ctx* c) {
+  if (!c->prof.on || c->prof.ev.empty()) return MI_OK;
+  MI_HIP(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->prof.cls.size(); ++i) {
+    float ms = 0.f;
+    MI_HIP(hipEventElapsedTime(&ms, c->prof.ev[2 * i], c->prof.ev[2 * i + 1]));
+    c->prof.ms[c->prof.cls[i]] += ms;
+    c->prof.launches[c->prof.cls[i]] += 1;
+    hipEventDestroy(c->prof.ev[2 * i]);
+    hipEventDestroy(c->prof.ev[2 * i + 1]);
+  }
+  c->prof.ev.clear();
+  c->prof.cls.clear();
+  return MI_OK;
+}
+
+// ---- linear dispatch --------------------------------------------------------------------
+// rows x K activations -> epilogue.  Token-generation sized inputs stream the weights
+// (GEMV); larger ones go through rmsnorm rows + MFMA GEMM.
+int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi, EpiArgs e) {
+  e.scale = L.scale;
+  e.bias = L.bias;
+  if (gemv_fits(rows, L.K)) {
+    Scope sc(c, MI_K_GEMV);
+    if (c->prof.on) c->prof.gemv_bytes += (double)L.bytes();
+    return launch_gemv(L.view(), rows, pro, p, epi, e, c->stream);
+  }
+  const uint16_t* x = p.x;
+  int ldx = p.ldx;
+  if (pro == PRO_NORM) {
+    Scope sc(c, MI_K_OTHER);
+    MI_TRY(launch_norm_rows(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->xn, c->stream));
+    x = c->xn;
+    ldx = L.K;
+  }
+  Scope sc(c, MI_K_GEMM);
+  return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
+}
+
+int all_reduce_partial(mi_ctx* c, int rows) {
+  if (c->cfg.tp_degree <= 1) return MI_OK;
+  Scope sc(c, MI_K_COMM);
+  ncclResult_t r = ncclAllReduce(c->partial, c->partial, (size_t)rows * c->H, ncclFloat, ncclSum, c->comm, c->stream);
+  if (r != ncclSuccess) {
+    set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return MI_ECOMM;
+  }
+  return MI_OK;
+}
+
+// The decoder stack over `rows` token rows whose ids/positions/slots are already in
+// d_ids/d_pos/d_slots.  decode: rows = B sequences (block tables d_bt [B, MB], lengths d_ctx).
+// prefill: rows = new tokens of ONE sequence at positions q_pos0.. (block table d_bt[0, :]).
+int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int logits_rows,
+               int logits_row0) {
+  const mi_model_config& k = c->cfg;
+  hipStream_t s = c->stream;
+  {
+    Scope sc(c, MI_K_OTHER);
+    MI_TRY(launch_embed(c->d_ids, c->embed, rows, c->H, c->resid[0], s));
+  }
+  int cur = 0;
+  bool have_partial = false;
+  for (int l = 0; l < k.num_layers; ++l) {
+    const LayerW& W = c->layers[l];
+    uint16_t* kpool = c->kv_pool + (size_t)l * 2 * c->kv_half;
+    uint16_t* vpool = kpool + c->kv_half;
+    {  // norm -> QKV -> RoPE -> q / KV pool
+      ProArgs p{};
+      p.resid_in = c->resid[cur];
+      p.partial = have_partial ? c->partial : nullptr;
+      p.resid_out = have_partial ? c->resid[cur ^ 1] : nullptr;
+      p.gain = W.g_in;
+      p.eps = k.rms_norm_eps;
+      EpiArgs e{};
+      e.q_out = c->qbuf; e.q_dim = c->q_dim; e.kv_dim = c->kv_dim; e.hd = c->hd; e.nkv = c->nkv_l;
+      e.pos = c->d_pos; e.slots = c->d_slots; e.rope_cos = c->rope_cos; e.rope_sin = c->rope_sin;
+      e.kpool = kpool; e.vpool = vpool; e.block_size = k.block_size;
+      MI_TRY(run_linear(c, W.qkv, rows, PRO_NORM, p, EPI_QKV, e));
+      if (have_partial) cur ^= 1;
+    }
+    if (decode) {
+      Scope sc(c, MI_K_ATTN_DECODE);
+      MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
+                                c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s));
+    } else {
+      Scope sc(c, MI_K_ATTN_PREFILL);
+      MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
+                                 c->nkv_l, c->hd, c->attn_out, s));
+    }
+    {  // O projection -> fp32 partial
+      ProArgs p{};
+      p.x = c->attn_out; p.ldx = c->q_dim;
+      EpiArgs e{};
+      e.out_f32 = c->partial; e.ld_out = c->H;
+      MI_TRY(run_linear(c, W.o, rows, PRO_BF16, p, EPI_F32, e));
+      MI_TRY(all_reduce_partial(c, rows));
+    }
+    {  // residual + norm -> gate|up -> SwiGLU
+      ProArgs p{};
+      p.resid_in = c->resid[cur]; p.partial = c->partial; p.resid_out = c->resid[cur ^ 1];
+      p.gain = W.g_post; p.eps = k.rms_norm_eps;
+      EpiArgs e{};
+      e.act_out = c->act; e.ld_act = c->I_l;
+      MI_TRY(run_linear(c, W.gu, rows, PRO_NORM, p, EPI_SWIGLU, e));
+      cur ^= 1;
+    }
+    {  // down projection -> fp32 partial
+      ProArgs p{};
+      p.x = c->act; p.ldx = c->I_l;
+      EpiArgs e{};
+      e.out_f32 = c->partial; e.ld_out = c->H;
+      MI_TRY(run_linear(c, W.down, rows, PRO_BF16, p, EPI_F32, e));
+      MI_TRY(all_reduce_partial(c, rows));
+    }
+    have_partial = true;
+  }
+  {  // final norm + lm_head on the rows that are sampled (loader.py:363: logits[:, -1, :])
+    ProArgs p{};
+    p.resid_in = c->resid[cur] + (size_t)logits_row0 * c->H;
+    p.partial = c->partial + (size_t)logits_row0 * c->H;
+    p.resid_out = nullptr;
+    p.gain = c->g_final; p.eps = k.rms_norm_eps;
+    EpiArgs e{};
+    e.out_f32 = c->logits; e.ld_out = c->V_l;
+    MI_TRY(run_linear(c, c->lm_head, logits_rows, PRO_NORM, p, EPI_F32, e));
+  }
+  if (k.tp_degree > 1) {
+    Scope sc(c, MI_K_COMM);
+    ncclResult_t r = ncclAllGather(c->logits, c->logits_all, (size_t)k.max_num_seqs * c->V_l, ncclFloat, c->comm, s);
+    if (r != ncclSuccess) {
+      set_error(std::string("ncclAllGather: ") + ncclGetErrorString(r));
+      return MI_ECOMM;
+    }
+  }
+  return MI_OK;
+}
+
+int fetch_logits(mi_ctx* c, int nrows, float* out) {
+  const mi_model_config& k = c->cfg;
+  const int V = k.vocab_size;
+  if (k.tp_degree <= 1) {
+    MI_HIP(hipMemcpyAsync(c->h_logits, c->logits, (size_t)nrows * V * 4, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_logits, (size_t)nrows * V * 4);
+    return MI_OK;
+  }
+  const size_t per_rank = (size_t)k.max_num_seqs * c->V_l;
+  MI_HIP(hipMemcpyAsync(c->h_logits, c->logits_all, per_rank * k.tp_degree * 4, hipMemcpyDeviceToHost, c->stream));
+  MI_HIP(hipStreamSynchronize(c->stream));
+  for (int r = 0; r < k.tp_degree; ++r)
+    for (int b = 0; b < nrows; ++b)
+      memcpy(out + (size_t)b * V + (size_t)r * c->V_l, c->h_logits + r * per_rank + (size_t)b * c->V_l, (size_t)c->V_l * 4);
+  return MI_OK;
+}
+
+// ---- weight loading ------------------------------------------------------------------
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int ensure_stage(mi_ctx* c, size_t elems, int rows) {
+  if (elems > c->stage_elems) {
+    if (c->stage_raw) hipFree(c->stage_raw);
+    if (c->stage_f32) hipFree(c->stage_f32);
+    MI_HIP(hipMalloc(&c->stage_raw, elems * 2));
+    MI_HIP(hipMalloc(reinterpret_cast<void**>(&c->stage_f32), elems * 4));
+    c->stage_elems = elems;
+  }
+  (void)rows;
+  return MI_OK;
+}
+
+// src: fp32 [rows_total, ld] on the device (the FULL HF tensor)
+int place_matrix(mi_ctx* c, Linear& L, const float* src, int rows_total, int ld, int src_row0, int n_rows,
+                 int src_col0, int rowmap, int dst_row0) {
+  QuantJob j{};
+  j.src = src; j.ld = ld; j.src_row0 = src_row0; j.src_col0 = src_col0; j.n_rows = n_rows; j.K = L.K;
+  j.rowmap = rowmap; j.hd = c->hd; j.dst_row0 = dst_row0; j.wd = L.wd; j.quant_type = c->cfg.quant_type;
+  j.dst = L.w; j.dst_scale = L.scale; j.tmp_rowmax = c->rowmax; j.src_rows_total = rows_total;
+  return run_quant_job(j, c->stream);
+}
+
+int place_vector(mi_ctx* c, float* dst, const float* host_f32, int n) {
+  MI_HIP(hipMemcpyAsync(dst, host_f32, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  MI_HIP(hipStreamSynchronize(c->stream));
+  return MI_OK;
+}
+
+// the tensor is on the device as fp32 [rows, cols] (cols = 1 for vectors is handled by the caller)
+int route_matrix(mi_ctx* c, const std::string& name, const float* dsrc, int rows, int cols) {
+  const mi_model_config& k = c->cfg;
+  const int T = k.tp_degree, r = k.tp_rank;
+  if (name == "model.embed_tokens.weight") {
+    MI_CHECK(rows == k.vocab_size && cols == c->H, "embed_tokens shape");
+    MI_TRY(launch_f32_to_bf16(dsrc, c->embed, (size_t)rows * cols, c->stream));
+    if (k.tie_word_embeddings) {
+      MI_TRY(place_matrix(c, c->lm_head, dsrc, rows, cols, r * c->V_l, c->V_l, 0, ROWMAP_PLAIN, 0));
+      c->have_lm_head = true;
+    }
+    return MI_OK;
+  }
+  if (name == "lm_head.weight") {
+    MI_CHECK(rows == k.vocab_size && cols == c->H, "lm_head shape");
+    MI_TRY(place_matrix(c, c->lm_head, dsrc, rows, cols, r * c->V_l, c->V_l, 0, ROWMAP_PLAIN, 0));
+    c->have_lm_head = true;
+    return MI_OK;
+  }
+  int l = -1;
+  if (sscanf(name.c_str(), "model.layers.%d.", &l) != 1 || l < 0 || l >= k.num_layers) return MI_OK;  // not ours
+  LayerW& W = c->layers[l];
+  const int I = k.intermediate_size;
+  if (ends_with(name, "self_attn.q_proj.weight")) {
+    MI_CHECK(rows == k.num_heads * c->hd && cols == c->H, "q_proj shape");
+    return place_matrix(c, W.qkv, dsrc, rows, cols, r * c->q_dim, c->q_dim, 0, ROWMAP_ROPE_PAIRS, 0);
+  }
+  if (ends_with(name, "self_attn.k_proj.weight")) {
+    MI_CHECK(rows == k.num_kv_heads * c->hd && cols == c->H, "k_proj shape");
+    return place_matrix(c, W.qkv, dsrc, rows, cols, c->kvh0 * c->hd, c->kv_dim, 0, ROWMAP_ROPE_PAIRS, c->q_dim);
+  }
+  if (ends_with(name, "self_attn.v_proj.weight")) {
+    MI_CHECK(rows == k.num_kv_heads * c->hd && cols == c->H, "v_proj shape");
+    return place_matrix(c, W.qkv, dsrc, rows, cols, c->kvh0 * c->hd, c->kv_dim, 0, ROWMAP_PLAIN, c->q_dim + c->kv_dim);
+  }
+  if (ends_with(name, "self_attn.o_proj.weight")) {
+    MI_CHECK(rows == c->H && cols == k.num_heads * c->hd, "o_proj shape");
+    return place_matrix(c, W.o, dsrc, rows, cols, 0, c->H, r * c->q_dim, ROWMAP_PLAIN, 0);
+  }
+  if (ends_with(name, "mlp.gate_proj.weight")) {
+    MI_CHECK(rows == I && cols == c->H, "gate_proj shape");
+    return place_matrix(c, W.gu, dsrc, rows, cols, r * c->I_l, c->I_l, 0, ROWMAP_EVERY_OTHER, 0);
+  }
+  if (ends_with(name, "mlp.up_proj.weight")) {
+    MI_CHECK(rows == I && cols == c->H, "up_proj shape");
+    return place_matrix(c, W.gu, dsrc, rows, cols, r * c->I_l, c->I_l, 0, ROWMAP_EVERY_OTHER, 1);
+  }
+  if (ends_with(name, "mlp.down_proj.weight")) {
+    MI_CHECK(rows == c->H && cols == I, "down_proj shape");
+    return place_matrix(c, W.down, dsrc, rows, cols, 0, c->H, r * c->I_l, ROWMAP_PLAIN, 0);
+  }
+  (void)T;
+  return MI_OK;
+}
+
+int route_vector(mi_ctx* c, const std::string& name, const std::vector<float>& v) {
+  const mi_model_config& k = c->cfg;
+  const int n = (int)v.size();
+  if (name == "model.norm.weight") {
+    MI_CHECK(n == c->H, "model.norm shape");
+    return place_vector(c, c->g_final, v.data(), n);
+  }
+  int l = -1;
+  if (sscanf(name.c_str(), "model.layers.%d.", &l) != 1 || l < 0 || l >= k.num_layers) return MI_OK;
+  LayerW& W = c->layers[l];
+  if (ends_with(name, "input_layernorm.weight")) { MI_CHECK(n == c->H, "input_layernorm shape"); return place_vector(c, W.g_in, v.data(), n); }
+  if (ends_with(name, "post_attention_layernorm.weight")) { MI_CHECK(n == c->H, "post_attention_layernorm shape"); return place_vector(c, W.g_post, v.data(), n); }
+  const bool qb = ends_with(name, "self_attn.q_proj.bias"), kb = ends_with(name, "self_attn.k_proj.bias"),
+             vb = ends_with(name, "self_attn.v_proj.bias");
+  if (qb || kb || vb) {
+    MI_CHECK(W.qkv.bias != nullptr, "bias tensor given but the config has qkv_bias = 0");
+    const int hd = c->hd;
+    const int src0 = qb ? k.tp_rank * c->q_dim : c->kvh0 * hd;
+    const int cnt = qb ? c->q_dim : c->kv_dim;
+    const int dst0 = qb ? 0 : (kb ? c->q_dim : c->q_dim + c->kv_dim);
+    MI_CHECK(n == (qb ? k.num_heads : k.num_kv_heads) * hd, "qkv bias shape");
+    std::vector<float> out(cnt);
+    for (int i = 0; i < cnt; ++i) {
+      int j = i;  // destination index of source element i
+      if (!vb) {
+        const int head = i / hd, d = i % hd;
+        j = head * hd + (d < hd / 2 ? 2 * d : 2 * (d - hd / 2) + 1);
+      }
+      out[j] = v[src0 + i];
+    }
+    return place_vector(c, W.qkv.bias + dst0, out.data(), cnt);
+  }
+  return MI_OK;
+}
+
+float bf16_bits_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
+  const int key = B * 65536 + MB;
+  if (!c->cfg.use_graphs || c->prof.on) return run_layers(c, B, true, B, MB, 0, B, 0);
+  auto it = c->graphs.find(key);
+  if (it == c->graphs.end()) {
+    // one eager pass first: sets every kernel's attributes outside of capture
+    MI_TRY(run_layers(c, B, true, B, MB, 0, B, 0));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    hipGraph_t g = nullptr;
+    MI_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_layers(c, B, true, B, MB, 0, B, 0);
+    hipError_t ce = hipStreamEndCapture(c->stream, &g);
+    if (rc != MI_OK) return rc;
+    MI_HIP(ce);
+    hipGraphExec_t ge = nullptr;
+    MI_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipGraphDestroy(g);
+    c->graphs[key] = ge;
+    return MI_OK;  // the eager pass already produced this step's logits
+  }
+  MI_HIP(hipGraphLaunch(it->second, c->stream));
+  return MI_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+const char* mi_last_error(void) { return mi::g_err.c_str(); }
+int mi_version(void) { return 1; }
+
+int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
+  MI_CHECK(cfg && out, "null argument");
+  const mi_model_config& k = *cfg;
+  MI_CHECK(k.num_layers > 0 && k.hidden_size > 0 && k.num_heads > 0 && k.num_kv_heads > 0, "bad geometry");
+  MI_CHECK(k.head_dim == 64 || k.head_dim == 128, "head_dim must be 64 or 128");
+  MI_CHECK(k.tp_degree >= 1 && k.tp_rank >= 0 && k.tp_rank < k.tp_degree, "bad tp_degree / tp_rank");
+  MI_CHECK(k.num_heads % k.tp_degree == 0, "num_heads must divide by tp_degree");
+  MI_CHECK(k.num_heads % k.num_kv_heads == 0, "num_heads must be a multiple of num_kv_heads");
+  MI_CHECK(k.intermediate_size % k.tp_degree == 0 && k.vocab_size % k.tp_degree == 0, "intermediate/vocab must divide by tp_degree");
+  MI_CHECK(k.block_size > 0 && k.block_size % 32 == 0, "block_size must be a positive multiple of 32");
+  MI_CHECK(k.num_blocks >= 2, "num_blocks must include the null block and at least one real block");
+  MI_CHECK(k.max_num_seqs >= 1 && k.max_num_seqs <= 16, "max_num_seqs must be 1..16");
+  MI_CHECK(k.max_model_len >= 1, "max_model_len");
+  MI_CHECK(k.weight_dtype >= MI_W_BF16 && k.weight_dtype <= MI_W_INT8, "weight_dtype");
+  MI_CHECK(k.quant_type == MI_Q_PER_TENSOR_SYMMETRIC || k.quant_type == MI_Q_PER_CHANNEL_SYMMETRIC, "quant_type");
+  int ndev = 0;
+  MI_HIP(hipGetDeviceCount(&ndev));
+  MI_CHECK(ndev > 0, "no HIP device: this library has no CPU fallback");
+  MI_CHECK(k.device_id >= 0 && k.device_id < ndev, "device_id out of range");
+  MI_HIP(hipSetDevice(k.device_id));
+
+  mi_ctx* c = new mi_ctx();
+  c->cfg = k;
+  MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  const int T = k.tp_degree;
+  c->H = k.hidden_size;
+  c->hd = k.head_dim;
+  c->nh_l = k.num_heads / T;
+  c->nkv_l = k.num_kv_heads >= T ? k.num_kv_heads / T : 1;
+  MI_CHECK(k.num_kv_heads >= T ? k.num_kv_heads % T == 0 : T % k.num_kv_heads == 0, "num_kv_heads vs tp_degree");
+  c->kvh0 = k.num_kv_heads >= T ? k.tp_rank * c->nkv_l : (k.tp_rank * c->nh_l) / (k.num_heads / k.num_kv_heads);
+  MI_CHECK(c->nh_l % c->nkv_l == 0 && c->nh_l / c->nkv_l <= 8, "q heads per kv head (per rank) must be 1..8");
+  c->q_dim = c->nh_l * c->hd;
+  c->kv_dim = c->nkv_l * c->hd;
+  c->I_l = k.intermediate_size / T;
+  c->V_l = k.vocab_size / T;
+  int maxb = k.max_model_len;
+  for (int i = 0; i < k.num_ctx_buckets && i < 8; ++i) maxb = std::max(maxb, k.ctx_buckets[i]);
+  c->max_rows = std::max(maxb, k.max_num_seqs);
+
+  const int wd = k.weight_dtype;
+  c->layers.resize(k.num_layers);
+  for (auto& W : c->layers) {
+    MI_TRY(alloc_linear(c, W.qkv, c->q_dim + 2 * c->kv_dim, c->H, wd, k.qkv_bias != 0));
+    MI_TRY(alloc_linear(c, W.o, c->H, c->q_dim, wd, false));
+    MI_TRY(alloc_linear(c, W.gu, 2 * c->I_l, c->H, wd, false));
+    MI_TRY(alloc_linear(c, W.down, c->H, c->I_l, wd, false));
+    MI_TRY(dmalloc(&W.g_in, (size_t)c->H, &c->weight_bytes));
+    MI_TRY(dmalloc(&W.g_post, (size_t)c->H, &c->weight_bytes));
+  }
+  MI_TRY(alloc_linear(c, c->lm_head, c->V_l, c->H, k.quantize_lm_head ? wd : MI_W_BF16, false));
+  MI_TRY(dmalloc(&c->g_final, (size_t)c->H, &c->weight_bytes));
+  MI_TRY(dmalloc(&c->embed, (size_t)k.vocab_size * c->H, &c->weight_bytes));
+  MI_TRY(dmalloc(&c->rowmax, (size_t)std::max(std::max(k.vocab_size, k.hidden_size), std::max(k.intermediate_size, k.num_heads * k.head_dim)) + 16));
+  *out = c;
+  return MI_OK;
+}
+
+int mi_ctx_destroy(mi_ctx* c) {
+  if (!c) return MI_OK;
+  hipSetDevice(c->cfg.device_id);
+  hipStreamSynchronize(c->stream);
+  for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+  if (c->comm) ncclCommDestroy(c->comm);
+  auto fl = [](Linear& L) { hipFree(L.w); hipFree(L.scale); hipFree(L.bias); };
+  for (auto& W : c->layers) { fl(W.qkv); fl(W.o); fl(W.gu); fl(W.down); hipFree(W.g_in); hipFree(W.g_post); }
+  fl(c->lm_head);
+  void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
+                  c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
+                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx};
+  for (void* p : ptrs) hipFree(p);
+  void* hptrs[] = {c->h_ids, c->h_pos, c->h_slots, c->h_bt, c->h_ctx, c->h_logits};
+  for (void* p : hptrs) if (p) hipHostFree(p);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return MI_OK;
+}
+
+int mi_load_weight(mi_ctx* c, const char* name_c, const void* host, int32_t dtype, const int64_t* shape, int32_t ndim) {
+  MI_CHECK(c && name_c && host && shape, "null argument");
+  MI_CHECK(!c->finalized, "mi_load_weight after mi_finalize");
+  MI_CHECK(dtype == MI_F32 || dtype == MI_BF16, "weights must be fp32 or bf16 on the host");
+  MI_CHECK(ndim == 1 || ndim == 2, "weights must be 1-D or 2-D");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  const std::string name(name_c);
+  if (ndim == 1) {
+    std::vector<float> v((size_t)shape[0]);
+    if (dtype == MI_F32) memcpy(v.data(), host, v.size() * 4);
+    else for (size_t i = 0; i < v.size(); ++i) v[i] = bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(host)[i]);
+    return route_vector(c, name, v);
+  }
+  const size_t elems = (size_t)shape[0] * (size_t)shape[1];
+  MI_TRY(ensure_stage(c, elems, (int)shape[0]));
+  if (dtype == MI_F32) {
+    MI_HIP(hipMemcpyAsync(c->stage_f32, host, elems * 4, hipMemcpyHostToDevice, c->stream));
+  } else {
+    MI_HIP(hipMemcpyAsync(c->stage_raw, host, elems * 2, hipMemcpyHostToDevice, c->stream));
+    MI_TRY(launch_bf16_to_f32(reinterpret_cast<const uint16_t*>(c->stage_raw), c->stage_f32, elems, c->stream));
+  }
+  MI_TRY(route_matrix(c, name, c->stage_f32, (int)shape[0], (int)shape[1]));
+  MI_HIP(hipStreamSynchronize(c->stream));  // the host buffer / staging may be reused by the caller
+  return MI_OK;
+}
+
+int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
+  MI_CHECK(c && !c->finalized, "bad state");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  const mi_model_config& k = c->cfg;
+  uint64_t tid = 1;
+  auto gen = [&](const std::string& name, int rows, int cols, float sd) -> int {
+    const size_t elems = (size_t)rows * cols;
+    MI_TRY(ensure_stage(c, elems, rows));
+    MI_TRY(launch_randn(c->stage_f32, elems, seed, tid++, sd, c->stream));
+    return route_matrix(c, name, c->stage_f32, rows, cols);
+  };
+  MI_TRY(gen("model.embed_tokens.weight", k.vocab_size, c->H, 1.0f));
+  char buf[128];
+  for (int l = 0; l < k.num_layers; ++l) {
+    auto nm = [&](const char* suf) { snprintf(buf, sizeof buf, "model.layers.%d.%s", l, suf); return std::string(buf); };
+    MI_TRY(gen(nm("self_attn.q_proj.weight"), k.num_heads * c->hd, c->H, std));
+    MI_TRY(gen(nm("self_attn.k_proj.weight"), k.num_kv_heads * c->hd, c->H, std));
+    MI_TRY(gen(nm("self_attn.v_proj.weight"), k.num_kv_heads * c->hd, c->H, std));
+    MI_TRY(gen(nm("self_attn.o_proj.weight"), c->H, k.num_heads * c->hd, std));
+    MI_TRY(gen(nm("mlp.gate_proj.weight"), k.intermediate_size, c->H, std));
+    MI_TRY(gen(nm("mlp.up_proj.weight"), k.intermediate_size, c->H, std));
+    MI_TRY(gen(nm("mlp.down_proj.weight"), c->H, k.intermediate_size, std));
+    MI_TRY(launch_fill_f32(c->layers[l].g_in, c->H, 1.0f, c->stream));
+    MI_TRY(launch_fill_f32(c->layers[l].g_post, c->H, 1.0f, c->stream));
+  }
+  MI_TRY(launch_fill_f32(c->g_final, c->H, 1.0f, c->stream));
+  if (!k.tie_word_embeddings) MI_TRY(gen("lm_head.weight", k.vocab_size, c->H, std));
+  MI_HIP(hipStreamSynchronize(c->stream));
+  return MI_OK;
+}
+
+int mi_finalize(mi_ctx* c) {
+  MI_CHECK(c && !c->finalized, "bad state");
+  MI_CHECK(c->have_lm_head, "lm_head.weight (or tied embed_tokens) was never loaded");
+  MI_CHECK(c->cfg.tp_degree == 1 || c->comm != nullptr, "tp_degree > 1: call mi_tp_init before mi_finalize");
+  const mi_model_config& k = c->cfg;
+  MI_HIP(hipSetDevice(k.device_id));
+  hipStream_t s = c->stream;
+  if (c->stage_raw) { hipFree(c->stage_raw); c->stage_raw = nullptr; }
+  if (c->stage_f32) { hipFree(c->stage_f32); c->stage_f32 = nullptr; }
+  c->stage_elems = 0;
+  // KV pool, zero-filled: stale or never-written rows must hold finite values
+  c->kv_half = (size_t)k.num_blocks * c->nkv_l * k.block_size * c->hd;
+  const size_t kv_elems = c->kv_half * 2 * k.num_layers;
+  MI_TRY(dmalloc(&c->kv_pool, kv_elems, &c->kv_bytes));
+  MI_HIP(hipMemsetAsync(c->kv_pool, 0, kv_elems * 2, s));
+  // RoPE tables (fp32 angles as HF computes them; llama3 rescale of the inverse frequencies)
+  {
+    const int half = c->hd / 2, P = k.max_model_len;
+    std::vector<float> inv(half), cs((size_t)P * half), sn((size_t)P * half);
+    for (int i = 0; i < half; ++i) {
+      float f = 1.0f / powf(k.rope_theta, (float)(2 * i) / (float)c->hd);
+      if (k.rope_type == MI_ROPE_LLAMA3) {
+        const float old = (float)k.rope_original_max_position;
+        const float wavelen = 2.0f * (float)M_PI / f;
+        const float lo_w = old / k.rope_low_freq_factor, hi_w = old / k.rope_high_freq_factor;
+        const float scaled = wavelen > lo_w ? f / k.rope_factor : f;
+        const float smooth = (old / wavelen - k.rope_low_freq_factor) / (k.rope_high_freq_factor - k.rope_low_freq_factor);
+        const float mid = (1.0f - smooth) * scaled / k.rope_factor + smooth * scaled;
+        const bool is_mid = !(wavelen < hi_w) && !(wavelen > lo_w);
+        f = is_mid ? mid : scaled;
+      }
+      inv[i] = f;
+    }
+    for (int p = 0; p < P; ++p)
+      for (int i = 0; i < half; ++i) {
+        const float ang = (float)p * inv[i];
+        cs[(size_t)p * half + i] = cosf(ang);
+        sn[(size_t)p * half + i] = sinf(ang);
+      }
+    MI_TRY(dmalloc(&c->rope_cos, cs.size(), &c->workspace_bytes));
+    MI_TRY(dmalloc(&c->rope_sin, sn.size(), &c->workspace_bytes));
+    MI_HIP(hipMemcpyAsync(c->rope_cos, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->rope_sin, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipStreamSynchronize(s));
+  }
+  const size_t R = (size_t)c->max_rows;
+  size_t* ws = &c->workspace_bytes;
+  MI_TRY(dmalloc(&c->resid[0], R * c->H, ws));
+  MI_TRY(dmalloc(&c->resid[1], R * c->H, ws));
+  MI_TRY(dmalloc(&c->partial, R * c->H, ws));
+  MI_TRY(dmalloc(&c->xn, R * std::max(c->H, c->I_l), ws));
+  MI_TRY(dmalloc(&c->qbuf, R * c->q_dim, ws));
+  MI_TRY(dmalloc(&c->attn_out, R * c->q_dim, ws));
+  MI_TRY(dmalloc(&c->act, R * c->I_l, ws));
+  MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
+  if (k.tp_degree > 1) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
+  MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
+  *ws += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
+  c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
+  const size_t nbt = (size_t)k.max_num_seqs * c->MB_cap;
+  MI_TRY(dmalloc(&c->d_ids, R, ws));
+  MI_TRY(dmalloc(&c->d_pos, R, ws));
+  MI_TRY(dmalloc(&c->d_slots, R, ws));
+  MI_TRY(dmalloc(&c->d_bt, nbt, ws));
+  MI_TRY(dmalloc(&c->d_ctx, (size_t)k.max_num_seqs, ws));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ids), R * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pos), R * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_slots), R * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bt), nbt * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctx), (size_t)k.max_num_seqs * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), (size_t)k.max_num_seqs * k.vocab_size * 4, hipHostMallocDefault));
+  MI_HIP(hipStreamSynchronize(s));
+  c->finalized = true;
+  return MI_OK;
+}
+
+int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const int64_t* position_ids,
+               const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
+               int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
+               float* logits_out) {
+  MI_CHECK(c && c->finalized, "mi_forward before mi_finalize");
+  MI_CHECK(input_ids && position_ids && block_table && slot_mapping && full_context_lens && computed_context_lens && logits_out, "null argument");
+  (void)seq_ids;  // block-layout KV: rows are addressed through block_table, not batch lines
+  const mi_model_config& k = c->cfg;
+  MI_CHECK(B >= 1 && B <= k.max_num_seqs, "batch size exceeds max_num_seqs");
+  MI_CHECK(S >= 1 && MB >= 1 && MB <= c->MB_cap && SM >= 1, "bad S / MB / SM");
+  MI_HIP(hipSetDevice(k.device_id));
+  hipStream_t s = c->stream;
+  const int V = k.vocab_size;
+  const int bs = k.block_size;
+
+  auto check_row = [&](int b, int full, int n_new) -> int {
+    MI_CHECK(full >= 1 && full <= k.max_model_len, "full_context_lens out of range");
+    MI_CHECK(n_new >= 1, "nothing to compute: computed_context_lens >= full_context_lens");
+    MI_CHECK(ceil_div(full, bs) <= MB, "block_table narrower than the context");
+    for (int j = 0; j < ceil_div(full, bs); ++j) {
+      const int64_t blk = block_table[(size_t)b * MB + j];
+      MI_CHECK(blk >= 0 && blk < k.num_blocks, "block_table entry out of range inside the live context");
+    }
+    return MI_OK;
+  };
+
+  if (S == 1) {  // ---- token generation -------------------------------------------------
+    for (int b = 0; b < B; ++b) {
+      const int full = (int)full_context_lens[b];
+      MI_TRY(check_row(b, full, 1));
+      const int64_t pos = position_ids[b], slot = slot_mapping[(size_t)b * SM];
+      MI_CHECK(pos >= 0 && pos < k.max_model_len, "position out of range");
+      MI_CHECK(input_ids[b] >= 0 && input_ids[b] < V, "token id out of range");
+      MI_CHECK(slot >= -1 && slot < (int64_t)k.num_blocks * bs, "slot out of range");
+      c->h_ids[b] = (int32_t)input_ids[b];
+      c->h_pos[b] = (int32_t)pos;
+      c->h_slots[b] = (int32_t)slot;
+      c->h_ctx[b] = full;
+      for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)block_table[(size_t)b * MB + j];
+    }
+    MI_HIP(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_slots, c->h_slots, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_ctx, c->h_ctx, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_bt, c->h_bt, (size_t)B * MB * 4, hipMemcpyHostToDevice, s));
+    MI_TRY(capture_or_launch_decode(c, B, MB));
+    MI_TRY(fetch_logits(c, B, logits_out));
+    return prof_collect(c);
+  }
+
+  // ---- context encoding: one sequence at a time (the reference schedules ctx_batch_size 1,
+  //      scheduler.py:116; loader.py:754-755) ------------------------------------------------
+  for (int b = 0; b < B; ++b) {
+    const int full = (int)full_context_lens[b], comp = (int)computed_context_lens[b];
+    const int n_new = full - comp;
+    MI_CHECK(comp >= 0 && full <= S, "context lengths inconsistent with the padded prompt");
+    MI_TRY(check_row(b, full, n_new));
+    MI_CHECK(n_new <= c->max_rows && n_new <= SM, "prompt longer than the largest bucket / slot_mapping");
+    for (int t = 0; t < n_new; ++t) {
+      const int64_t id = input_ids[(size_t)b * S + comp + t], pos = position_ids[(size_t)b * S + comp + t];
+      const int64_t slot = slot_mapping[(size_t)b * SM + t];
+      MI_CHECK(id >= 0 && id < V, "token id out of range");
+      MI_CHECK(pos >= 0 && pos < k.max_model_len, "position out of range");
+      MI_CHECK(slot >= -1 && slot < (int64_t)k.num_blocks * bs, "slot out of range");
+      c->h_ids[t] = (int32_t)id;
+      c->h_pos[t] = (int32_t)pos;
+      c->h_slots[t] = (int32_t)slot;
+    }
+    for (int j = 0; j < MB; ++j) c->h_bt[j] = (int32_t)block_table[(size_t)b * MB + j];
+    MI_HIP(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_slots, c->h_slots, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
+    MI_HIP(hipMemcpyAsync(c->d_bt, c->h_bt, (size_t)MB * 4, hipMemcpyHostToDevice, s));
+    MI_TRY(run_layers(c, n_new, false, 1, MB, comp, 1, n_new - 1));
+    MI_TRY(fetch_logits(c, 1, logits_out + (size_t)b * V));
+  }
+  return prof_collect(c);
+}
+
+int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {
+  MI_CHECK(c && o, "null argument");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  size_t fr = 0, tot = 0;
+  MI_HIP(hipMemGetInfo(&fr, &tot));
+  o->kv_bytes = (int64_t)c->kv_bytes; o->weight_bytes = (int64_t)c->weight_bytes;
+  o->workspace_bytes = (int64_t)c->workspace_bytes;
+  o->device_free_bytes = (int64_t)fr; o->device_total_bytes = (int64_t)tot;
+  o->num_blocks = c->cfg.num_blocks; o->block_size = c->cfg.block_size;
+  o->num_kv_heads_local = c->nkv_l; o->head_dim = c->hd; o->num_layers = c->cfg.num_layers;
+  return MI_OK;
+}
+
+void* mi_stream(mi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int mi_profile_enable(mi_ctx* c, int32_t on) {
+  MI_CHECK(c, "null argument");
+  MI_TRY(prof_collect(c));
+  c->prof.on = on != 0;
+  if (on) {
+    memset(c->prof.launches, 0, sizeof c->prof.launches);
+    memset(c->prof.ms, 0, sizeof c->prof.ms);
+    c->prof.gemv_bytes = 0;
+  }
+  return MI_OK;
+}
+int mi_profile_read(mi_ctx* c, int32_t* launches, float* ms, double* gemv_weight_bytes) {
+  MI_CHECK(c && launches && ms, "null argument");
+  MI_TRY(prof_collect(c));
+  for (int i = 0; i < MI_K_NUM; ++i) { launches[i] = c->prof.launches[i]; ms[i] = c->prof.ms[i]; }
+  if (gemv_weight_bytes) *gemv_weight_bytes = c->prof.gemv_bytes;
+  return MI_OK;
+}
+
+int mi_tp_unique_id(void* out128) {
+  MI_CHECK(out128, "null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r)); return MI_ECOMM; }
+  memcpy(out128, &id, 128);
+  return MI_OK;
+}
+int mi_tp_init(mi_ctx* c, const void* id128) {
+  MI_CHECK(c && id128, "null argument");
+  MI_CHECK(!c->comm, "mi_tp_init called twice");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclResult_t r = ncclCommInitRank(&c->comm, c->cfg.tp_degree, id, c->cfg.tp_rank);
+  if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return MI_ECOMM; }
+  return MI_OK;
+}
+
+// ---- per-kernel entry points ------------------------------------------------------------
+int mi_op_quantize_weight(const float* w, int32_t N, int32_t K, int32_t wd, int32_t qt, void* tiled_out,
+                          float* scale_out, void* stream) {
+  MI_CHECK(w && tiled_out && scale_out, "null argument");
+  MI_CHECK(N % 16 == 0 && K % 64 == 0, "N % 16 == 0 and K % 64 == 0 required");
+  float* rowmax = nullptr;
+  MI_HIP(hipMalloc(reinterpret_cast<void**>(&rowmax), ((size_t)N + 16) * 4));
+  QuantJob j{};
+  j.src = w; j.ld = K; j.src_row0 = 0; j.src_col0 = 0; j.n_rows = N; j.K = K; j.rowmap = ROWMAP_PLAIN; j.hd = 0;
+  j.dst_row0 = 0; j.wd = wd; j.quant_type = qt; j.dst = tiled_out; j.dst_scale = scale_out; j.tmp_rowmax = rowmax;
+  j.src_rows_total = N;
+  int rc = run_quant_job(j, (hipStream_t)stream);
+  hipStreamSynchronize((hipStream_t)stream);
+  hipFree(rowmax);
+  return rc;
+}
+int mi_op_untile_weight(const void* tiled, int32_t N, int32_t K, int32_t wd, void* q_out, void* stream) {
+  MI_CHECK(tiled && q_out, "null argument");
+  return launch_untile(tiled, N, K, wd, q_out, (hipStream_t)stream);
+}
+int mi_op_qlinear(const void* x, int32_t M, const void* w_tiled, const float* scale, const float* bias, int32_t N,
+                  int32_t K, int32_t wd, float* y, int32_t force_path, void* stream) {
+  MI_CHECK(x && w_tiled && scale && y, "null argument");
+  LinearW W{w_tiled, N, K, wd};
+  EpiArgs e{};
+  e.scale = scale; e.bias = bias; e.out_f32 = y; e.ld_out = N;
+  ProArgs p{};
+  p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = K;
+  const bool gemv = force_path == 1 || (force_path == 0 && gemv_fits(M, K));
+  if (gemv) return launch_gemv(W, M, PRO_BF16, p, EPI_F32, e, (hipStream_t)stream);
+  return launch_gemm(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
+}
+int mi_op_rmsnorm(const float* x, const float* g, int32_t T, int32_t H, float eps, void* y, void* stream) {
+  MI_CHECK(x && g && y, "null argument");
+  return launch_norm_rows(x, nullptr, nullptr, g, T, H, eps, reinterpret_cast<uint16_t*>(y), (hipStream_t)stream);
+}
+int mi_op_kv_write(const void* k, const void* v, const int64_t* slots, int32_t T, int32_t nkv, int32_t hd, void* pool,
+                   int32_t num_blocks, int32_t block_size, void* stream) {
+  MI_CHECK(k && v && slots && pool, "null argument");
+  uint16_t* kp = reinterpret_cast<uint16_t*>(pool);
+  uint16_t* vp = kp + (size_t)num_blocks * nkv * block_size * hd;
+  return launch_kv_write(reinterpret_cast<const uint16_t*>(k), reinterpret_cast<const uint16_t*>(v), slots, T, nkv, hd,
+                         kp, vp, block_size, (hipStream_t)stream);
+}
+int64_t mi_op_attn_scratch_bytes(int32_t B, int32_t nh, int32_t hd) { return (int64_t)attn_scratch_bytes(B, nh, hd); }
+int mi_op_paged_attn_decode(const void* q, const void* pool, int32_t num_blocks, int32_t block_size,
+                            const int32_t* block_table, int32_t MB, const int32_t* ctx_lens, int32_t B, int32_t nh,
+                            int32_t nkv, int32_t hd, void* out, void* scratch, void* stream) {
+  MI_CHECK(q && pool && block_table && ctx_lens && out && scratch, "null argument");
+  const uint16_t* kp = reinterpret_cast<const uint16_t*>(pool);
+  const uint16_t* vp = kp + (size_t)num_blocks * nkv * block_size * hd;
+  return launch_attn_decode(reinterpret_cast<const uint16_t*>(q), kp, vp, block_size, block_table, MB, ctx_lens, B, nh,
+                            nkv, hd, reinterpret_cast<uint16_t*>(out), scratch, (hipStream_t)stream);
+}
+int mi_op_paged_attn_prefill(const void* q, int32_t T, int32_t q_pos0, const void* pool, int32_t num_blocks,
+                             int32_t block_size, const int32_t* block_table, int32_t MB, int32_t nh, int32_t nkv,
+                             int32_t hd, void* out, void* stream) {
+  MI_CHECK(q && pool && block_table && out, "null argument");
+  MI_CHECK(ceil_div(q_pos0 + T, block_size) <= MB, "block_table narrower than the context");
+  const uint16_t* kp = reinterpret_cast<const uint16_t*>(pool);
+  const uint16_t* vp = kp + (size_t)num_blocks * nkv * block_size * hd;
+  return launch_attn_prefill(reinterpret_cast<const uint16_t*>(q), T, q_pos0, kp, vp, block_size, block_table, nh, nkv,
+                             hd, reinterpret_cast<uint16_t*>(out), (hipStream_t)stream);
+}
+
+}  // extern "C"
