@@ -162,24 +162,38 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
   }
 }
 
+// Merge the context splits of one (sequence, head) in split order.  All partials are
+// fetched before the first use (kAttnMaxSplits is a compile-time bound), so the kernel is
+// one L2 round trip deep.
 template <int HD>
 __global__ __launch_bounds__(HD) void attn_combine_kernel(const float* __restrict__ o_part, const float* __restrict__ ml_part,
                                                           int NS, int nh, uint16_t* __restrict__ out) {
   const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const size_t row0 = ((size_t)b * nh + head) * NS;
+  float mv[kAttnMaxSplits], lv[kAttnMaxSplits], ov[kAttnMaxSplits];
+#pragma unroll
+  for (int s = 0; s < kAttnMaxSplits; ++s) {
+    const bool ok = s < NS;
+    const float2 ml = ok ? *reinterpret_cast<const float2*>(ml_part + (row0 + s) * 2) : make_float2(-INFINITY, 0.f);
+    mv[s] = ml.x;
+    lv[s] = ml.y;
+    ov[s] = ok ? o_part[(row0 + s) * HD + d] : 0.f;
+  }
   float M = -INFINITY;
-  for (int s = 0; s < NS; ++s) M = fmaxf(M, ml_part[(row0 + s) * 2]);
+#pragma unroll
+  for (int s = 0; s < kAttnMaxSplits; ++s) M = fmaxf(M, mv[s]);
   float acc = 0.f, L = 0.f;
-  for (int s = 0; s < NS; ++s) {
-    const float f = sexp2(ml_part[(row0 + s) * 2], M);
-    acc += f * o_part[(row0 + s) * HD + d];
-    L += f * ml_part[(row0 + s) * 2 + 1];
+#pragma unroll
+  for (int s = 0; s < kAttnMaxSplits; ++s) {
+    const float f = sexp2(mv[s], M);
+    acc += f * ov[s];
+    L += f * lv[s];
   }
   out[((size_t)b * nh + head) * HD + d] = f32_to_bf16(acc / L);
 }
 
 int attn_decode_splits(int B, int nkv) {
-  int ns = ceil_div(512, B * nkv);
+  int ns = 256 / (B * nkv);  // ~one work-group per CU; >= 4 tiles (one per wave) each at 1k context
   return ns < 1 ? 1 : (ns > kAttnMaxSplits ? kAttnMaxSplits : ns);
 }
 size_t attn_scratch_bytes(int B, int nh, int hd) {

@@ -7,16 +7,17 @@
 namespace mi {
 
 // What happens to the fp32 accumulator tile D[n][m] once the contraction is done.
-enum { EPI_F32 = 0, EPI_QKV = 1, EPI_SWIGLU = 2 };
+enum { EPI_F32 = 0, EPI_QKV = 1, EPI_SWIGLU = 2, EPI_RESID = 3 };
 // Where the bf16 activations come from.
-enum { PRO_BF16 = 0, PRO_NORM = 1 };
+enum { PRO_BF16 = 0, PRO_NORM = 1, PRO_NORM_PARTIAL = 2 };  // callers pass PRO_BF16 / PRO_NORM; PARTIAL is picked when ProArgs::partial is set
 
 struct EpiArgs {
   const float* scale;  // [N] per-output-row dequant scale
   const float* bias;   // [N] or nullptr
-  // EPI_F32: out[m * ld_out + n]
+  // EPI_F32: out[m * ld_out + n] = y;  EPI_RESID: out = resid_in[m * ld_out + n] + y
   float* out_f32;
   int ld_out;
+  const float* resid_in;
   // EPI_QKV: rows [0,q_dim) -> RoPE -> q_out; [q_dim, q_dim+kv_dim) -> RoPE -> K pool;
   // the rest -> V pool.  Rows of every q/k head are stored pair-interleaved
   // (2i <- d=i, 2i+1 <- d=i+hd/2) so a lane owns both halves of a rotation.

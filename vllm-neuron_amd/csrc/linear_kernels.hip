@@ -32,6 +32,9 @@ namespace mi {
 // Epilogue
 // =====================================================================================
 template <int EPI>
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n0, f32x4_t v);
+
+template <int EPI>
 __device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_t v) {
   const float4 sc = *reinterpret_cast<const float4*>(e.scale + n0);
   v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
@@ -39,9 +42,33 @@ __device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_
     const float4 b = *reinterpret_cast<const float4*>(e.bias + n0);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
   }
+  epilogue_store<EPI>(e, m, n0, v);
+}
+
+// GEMV form: the scales / biases of the row-tiles a work-group owns were copied to LDS at
+// kernel start, so the epilogue never queues a global load behind the weight stream (vmcnt
+// retires in order: a late scale load would drain the whole prefetch).
+template <int EPI>
+__device__ __forceinline__ void epilogue_lds(const EpiArgs& e, int m, int n0, const float* sc4, const float* b4,
+                                             f32x4_t v) {
+  const float4 sc = *reinterpret_cast<const float4*>(sc4);
+  v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+  if (b4) {
+    const float4 b = *reinterpret_cast<const float4*>(b4);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  epilogue_store<EPI>(e, m, n0, v);
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n0, f32x4_t v) {
   if constexpr (EPI == EPI_F32) {
     *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ld_out + n0) =
         make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_RESID) {  // residual stream: out = resid_in + y (fp32)
+    const float4 r = *reinterpret_cast<const float4*>(e.resid_in + (size_t)m * e.ld_out + n0);
+    *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ld_out + n0) =
+        make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
   } else if constexpr (EPI == EPI_SWIGLU) {
     const float a0 = v[0] / (1.f + __expf(-v[0])) * v[1];
     const float a1 = v[2] / (1.f + __expf(-v[2])) * v[3];
@@ -78,12 +105,14 @@ __device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_
 // =====================================================================================
 // GEMV (token generation)
 // =====================================================================================
-// LDS: [x fragments: K/8 chunks * M * 16 B][red: 2 * WAVES * 64 lanes * 16 B]
+// LDS: [x fragments: K/8 chunks * M * 16 B][zero slot 16 B][red: 2 * WAVES * 64 lanes * 16 B][scales][biases]
 constexpr int kGemvWaves = 8;
-constexpr int kGemvU = 8;  // 1 KiB loads in flight per wave per batch (two batches live)
+constexpr int kGemvU = 8;  // 1 KiB loads per batch; two batches in flight per wave
 
+constexpr int kGemvMaxTilesPerWg = 64;  // row-tiles one work-group may own (scale/bias cache)
 size_t gemv_lds_bytes(int M, int K) {
-  return (size_t)M * K * 2 + 2 * kGemvWaves * 64 * 16;
+  // x image, zero slot, reduction buffers, scale + bias cache
+  return (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16 + 2 * kGemvMaxTilesPerWg * 16 * 4;
 }
 bool gemv_fits(int M, int K) { return M <= 16 && gemv_lds_bytes(M, K) <= 160 * 1024; }
 
@@ -98,174 +127,341 @@ __device__ __forceinline__ int xfrag_slot(int c8, int m, int M) {
   }
 }
 
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Stage the activations into LDS in MFMA-fragment order.
+//
+// Rows go 4 at a time with CLAMPED indices (no predication), so all global loads of a group
+// are in flight together: one L2 round trip per group when K <= 8 * threads.
+// (A wave's loads retire in order, so these operands arrive behind the weight batch that was
+// requested just before; moving them in front of it is the next step for the short kernels.)
 template <int WD, int PRO>
 __device__ __forceinline__ void gemv_stage_x(const ProArgs& p, int M, int K, uint4* xf, float* red_f) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int nchunk = K >> 3;
   if constexpr (PRO == PRO_BF16) {
-    for (int i = tid; i < M * nchunk; i += nthr) {
-      const int m = i / nchunk, c8 = i - m * nchunk;
-      xf[xfrag_slot<WD>(c8, m, M)] =
-          *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+    const int total = M * nchunk;
+    bool first = true;
+    for (int i0 = tid; i0 < total || first; i0 += 4 * nthr) {
+      uint4 v0, v1, v2, v3;
+      int s0, s1, s2, s3;
+      auto ld = [&](int i, uint4& v, int& slot) {
+        const int ic = min(i, total - 1);   // clamp instead of branching: 4 loads in flight
+        const int m = ic / nchunk, c8 = ic - m * nchunk;
+        v = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+        slot = xfrag_slot<WD>(c8, m, M);
+      };
+      ld(i0, v0, s0);
+      ld(i0 + nthr, v1, s1);
+      ld(i0 + 2 * nthr, v2, s2);
+      ld(i0 + 3 * nthr, v3, s3);
+      first = false;
+      if (i0 < total) xf[s0] = v0;
+      if (i0 + nthr < total) xf[s1] = v1;
+      if (i0 + 2 * nthr < total) xf[s2] = v2;
+      if (i0 + 3 * nthr < total) xf[s3] = v3;
     }
   } else {
     // h = resid_in (+ partial); rmsnorm in fp32; x = bf16(h * rsqrt(mean h^2 + eps) * gain)
     const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-    for (int m = 0; m < M; ++m) {
-      float ss = 0.f;
-      for (int c8 = tid; c8 < nchunk; c8 += nthr) {
-        const float* hp = p.resid_in + (size_t)m * K + c8 * 8;
-        float4 a = *reinterpret_cast<const float4*>(hp), b = *reinterpret_cast<const float4*>(hp + 4);
-        if (p.partial) {
-          const float* pp = p.partial + (size_t)m * K + c8 * 8;
-          const float4 pa = *reinterpret_cast<const float4*>(pp), pb = *reinterpret_cast<const float4*>(pp + 4);
-          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+    const bool fast = nchunk <= nthr;   // one 8-element chunk per thread and row: h stays in registers
+    for (int m0 = 0; m0 < M; m0 += 4) {
+      int row[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[r] = min(m0 + r, M - 1);
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      float h[4][8], g[8];
+      const int c0 = min(tid, nchunk - 1);
+      if (fast) {
+        load8(p.gain + c0 * 8, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c0 * 8, h[r]);
+        if constexpr (PRO == PRO_NORM_PARTIAL) {
+          float pv[4][8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c0 * 8, pv[r]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
         }
-        ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        if (tid < nchunk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
+        }
+      } else {
+        for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
+          if constexpr (PRO == PRO_NORM_PARTIAL) {
+            float pv[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c8 * 8, pv[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
+        }
       }
-      ss = wave_sum(ss);
-      if (lane == 0) red_f[m * 16 + wave] = ss;
-    }
-    __syncthreads();
-    for (int m = 0; m < M; ++m) {
-      float tot = 0.f;
-      for (int w = 0; w < nw; ++w) tot += red_f[m * 16 + w];
-      const float rinv = rsqrtf(tot / (float)K + p.eps);
-      for (int c8 = tid; c8 < nchunk; c8 += nthr) {
-        const size_t o = (size_t)m * K + c8 * 8;
-        float4 a = *reinterpret_cast<const float4*>(p.resid_in + o), b = *reinterpret_cast<const float4*>(p.resid_in + o + 4);
-        if (p.partial) {
-          const float4 pa = *reinterpret_cast<const float4*>(p.partial + o), pb = *reinterpret_cast<const float4*>(p.partial + o + 4);
-          a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-          b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = wave_sum(ss[r]);
+        if (lane == 0) red_f[(m0 + r) * 16 + wave] = t;
+      }
+      __syncthreads();
+      float rinv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tot = 0.f;
+        for (int w = 0; w < nw; ++w) tot += red_f[(m0 + r) * 16 + w];
+        rinv[r] = rsqrtf(tot / (float)K + p.eps);
+      }
+      auto emit = [&](int c8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m0 + r < M) {
+            const size_t o = (size_t)(m0 + r) * K + c8 * 8;
+            if (p.resid_out && blockIdx.x == 0) {
+              *reinterpret_cast<float4*>(p.resid_out + o) = make_float4(h[r][0], h[r][1], h[r][2], h[r][3]);
+              *reinterpret_cast<float4*>(p.resid_out + o + 4) = make_float4(h[r][4], h[r][5], h[r][6], h[r][7]);
+            }
+            uint4 o4;
+            o4.x = pack_bf16x2(h[r][0] * rinv[r] * g[0], h[r][1] * rinv[r] * g[1]);
+            o4.y = pack_bf16x2(h[r][2] * rinv[r] * g[2], h[r][3] * rinv[r] * g[3]);
+            o4.z = pack_bf16x2(h[r][4] * rinv[r] * g[4], h[r][5] * rinv[r] * g[5]);
+            o4.w = pack_bf16x2(h[r][6] * rinv[r] * g[6], h[r][7] * rinv[r] * g[7]);
+            xf[xfrag_slot<WD>(c8, m0 + r, M)] = o4;
+          }
+      };
+      if (fast) {
+        if (tid < nchunk) emit(tid);
+      } else {
+        // second pass re-reads h (L2-hot; again all rows of the group in one round trip)
+        for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+          load8(p.gain + c8 * 8, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
+          if constexpr (PRO == PRO_NORM_PARTIAL) {
+            float pv[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c8 * 8, pv[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
+          }
+          emit(c8);
         }
-        if (p.resid_out && blockIdx.x == 0) {
-          *reinterpret_cast<float4*>(p.resid_out + o) = a;
-          *reinterpret_cast<float4*>(p.resid_out + o + 4) = b;
-        }
-        const float4 g0 = *reinterpret_cast<const float4*>(p.gain + c8 * 8), g1 = *reinterpret_cast<const float4*>(p.gain + c8 * 8 + 4);
-        uint4 o4;
-        o4.x = pack_bf16x2(a.x * rinv * g0.x, a.y * rinv * g0.y);
-        o4.y = pack_bf16x2(a.z * rinv * g0.z, a.w * rinv * g0.w);
-        o4.z = pack_bf16x2(b.x * rinv * g1.x, b.y * rinv * g1.y);
-        o4.w = pack_bf16x2(b.z * rinv * g1.z, b.w * rinv * g1.w);
-        xf[xfrag_slot<WD>(c8, m, M)] = o4;
       }
     }
   }
 }
 
-template <int WD, int PRO, int EPI>
+// Work decomposition.  A work-group is 8 waves; KS of them (KS in {1,2,4,8}, chosen on the
+// host from the number of row-tiles) split the K dimension of ONE row-tile, so a work-group
+// covers 8/KS row-tiles at a time.  KS = 1: waves never meet (no barrier, no LDS reduction).
+// The hot loop is branch-free: weight loads are unconditional (addresses clamped into the
+// wave's slice) and out-of-range k-tiles / padding columns read a zeroed LDS slot instead of
+// being predicated off, so hipcc can keep counted vmcnt waits and 2 x U loads in flight.
+template <int WD, int PRO, int EPI, int KS>
 __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __restrict__ W, int NT, int KT,
                                                                int M, int K, ProArgs p, EpiArgs e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* xf = reinterpret_cast<uint4*>(smem);
-  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2);
+  const int zero_slot = (M * K) >> 3;  // one extra 16-byte slot of zeros behind the image
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2 + 16);
+  float* sc_lds = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16);
+  float* bi_lds = sc_lds + kGemvMaxTilesPerWg * 16;
+  constexpr int TPW = kGemvWaves / KS;  // row-tiles per work-group pass
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  // this wave's K-slice (in tiles), identical for every row-tile
-  const int ktw = ceil_div(KT, kGemvWaves);
-  const int kbeg = min(wave * ktw, KT), kend = min(kbeg + ktw, KT);
-  const int nb = max(1, ceil_div(ktw, kGemvU));  // batches per row-tile: SAME for every wave (barriers)
-  const int my_tiles = blockIdx.x < NT ? ceil_div(NT - blockIdx.x, gridDim.x) : 0;
-  const int total = my_tiles * nb;
+  const int tsub = wave / KS, kslice = wave % KS;
+  const int ktw = ceil_div(KT, KS);
+  const int kbeg = min(kslice * ktw, KT), kend = min(kbeg + ktw, KT);
+  const int klast = max(kend - 1, 0);
+  const int nb = ceil_div(ktw, kGemvU);  // batches per row-tile, same for every wave
+  const int units = ceil_div(NT, TPW);
+  const int my_units = blockIdx.x < units ? ceil_div(units - blockIdx.x, gridDim.x) : 0;
+  const int total = my_units * nb;
+  const bool col_ok = c < M;
 
-  uint4 bufA[kGemvU], bufB[kGemvU];
-  auto issue = [&](uint4 (&buf)[kGemvU], int i) {
-    const int tile = blockIdx.x + (i / nb) * gridDim.x;
+  // Two batches of kGemvU x 1 KiB are in flight per wave (16 KiB); two work-groups of 8 waves
+  // per CU keep 256 KiB per CU moving.
+  u32x4_t bufA[kGemvU], bufB[kGemvU];
+  // Two-buffer software pipeline; issue() is unconditional (index clamped: past the end the
+  // last batch is simply requested again, an L2 hit) so the loop body is branch-free.
+  auto issue = [&](u32x4_t (&buf)[kGemvU], int i) {
+    i = min(i, total - 1);
+    const int tile = min((int)(blockIdx.x + (i / nb) * gridDim.x) * TPW + tsub, NT - 1);
     const int kt0 = kbeg + (i % nb) * kGemvU;
-    const uint4* base = W + ((size_t)tile * KT + kt0) * 64 + lane;
+    const uint4* base = W + (size_t)tile * KT * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < kGemvU; ++u)
-      if (kt0 + u < kend) buf[u] = nt_load16(base + (size_t)u * 64);
+    for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * 64);
   };
 
-  if (total > 0) issue(bufA, 0);          // weights start moving before x is staged
+  // scale / bias of local tile slot j = (pass * TPW + sub-tile), 16 floats each: requested
+  // before the weights (see gemv_stage_x), parked in LDS afterwards
+  const int nsc = my_units * TPW * 16;
+  float scv[2], biv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = min(tid + q * (int)blockDim.x, nsc - 1);
+    const int slot = j >> 4, r = j & 15;
+    const int tile = min((int)(blockIdx.x + (slot / TPW) * gridDim.x) * TPW + (slot % TPW), NT - 1);
+    scv[q] = e.scale[tile * 16 + r];
+    biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
+  }
+  if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
+  issue(bufA, 0);
   gemv_stage_x<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = tid + q * (int)blockDim.x;
+    if (j < nsc) {
+      sc_lds[j] = scv[q];
+      bi_lds[j] = biv[q];
+    }
+  }
   __syncthreads();
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int parity = 0;
-  auto process = [&](uint4 (&buf)[kGemvU], int i) {
-    const int kt0 = kbeg + (i % nb) * kGemvU;
-#pragma unroll
-    for (int u = 0; u < kGemvU; ++u) {
-      const int kt = kt0 + u;
-      if (kt < kend) {
-        if constexpr (WD == MI_W_BF16) {
-          bf16x8_t b = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (c < M) b = __builtin_bit_cast(bf16x8_t, xf[(kt * 4 + g) * M + c]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, buf[u]), b, acc, 0, 0, 0);
-        } else {
-          bf16x8_t b0 = {0, 0, 0, 0, 0, 0, 0, 0}, b1 = b0;
-          if (c < M) {
-            b0 = __builtin_bit_cast(bf16x8_t, xf[((kt * 2 + 0) * 4 + g) * M + c]);
-            b1 = __builtin_bit_cast(bf16x8_t, xf[((kt * 2 + 1) * 4 + g) * M + c]);
-          }
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(buf[u].x, buf[u].y), b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(buf[u].z, buf[u].w), b1, acc, 0, 0, 0);
-        }
-      }
+  auto step = [&](u32x4_t w, int kt) {
+    const bool ok = col_ok && kt < kend;
+    if constexpr (WD == MI_W_BF16) {
+      const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xf[ok ? (kt * 4 + g) * M + c : zero_slot]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), b, acc, 0, 0, 0);
+    } else {
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 0) * 4 + g) * M + c : zero_slot]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 1) * 4 + g) * M + c : zero_slot]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
     }
-    if ((i % nb) == nb - 1) {  // row-tile finished: combine the K-slices in wave order
-      const int seq = i / nb;
-      const int tile = blockIdx.x + seq * gridDim.x;
+  };
+  auto finish_tile = [&](int i) {
+    const int tile = (int)(blockIdx.x + (i / nb) * gridDim.x) * TPW + tsub;
+    const int lslot = ((i / nb) * TPW + tsub) * 16 + g * 4;
+    const float* sc4 = sc_lds + lslot;
+    const float* b4 = e.bias ? bi_lds + lslot : nullptr;
+    if constexpr (KS == 1) {
+      if (col_ok && tile < NT) epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, acc);
+    } else {  // combine the K-slices in wave order (deterministic)
       red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
       __syncthreads();
-      if (wave == (seq % kGemvWaves)) {
-        f32x4_t s = red[(parity * kGemvWaves) * 64 + lane];
+      if (kslice == 0) {
+        f32x4_t s = red[(parity * kGemvWaves + wave) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < kGemvWaves; ++w) {
-          const f32x4_t t = red[(parity * kGemvWaves + w) * 64 + lane];
+        for (int w = 1; w < KS; ++w) {
+          const f32x4_t t = red[(parity * kGemvWaves + wave + w) * 64 + lane];
           s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
-        if (c < M) epilogue<EPI>(e, c, tile * 16 + g * 4, s);
+        if (col_ok && tile < NT) epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s);
       }
       parity ^= 1;
-      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+    acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  static_assert(kGemvU == 8, "the wait ladders below are written for 8 loads per batch");
+  auto process = [&](u32x4_t (&buf)[kGemvU], int i) {
+    const int kt0 = kbeg + (i % nb) * kGemvU;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) step(buf[u], kt0 + u);
+    if ((i % nb) == nb - 1) finish_tile(i);
   };
 
   for (int i = 0; i < total; i += 2) {
-    if (i + 1 < total) issue(bufB, i + 1);
+    issue(bufB, i + 1);
     process(bufA, i);
-    if (i + 1 < total) {
-      if (i + 2 < total) issue(bufA, i + 2);
-      process(bufB, i + 1);
-    }
+    issue(bufA, i + 2);
+    if (i + 1 < total) process(bufB, i + 1);
   }
 }
 
-template <int WD, int PRO, int EPI>
-static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+static int gemv_pick_ks(int NT, int KT, int slots) {
+  // `slots` work-groups are resident at once.  Prefer the K-split that (1) needs the fewest
+  // passes of work-groups over the chip, then (2) fills the most slots, then (3) splits K
+  // least (KS = 1 needs no barrier at all).
+  int best = 8, best_pass = 1 << 30, best_busy = 0;
+  for (int ks = 1; ks <= 8; ks *= 2) {
+    if (KT < ks) break;
+    const int units = ceil_div(NT, kGemvWaves / ks);
+    const int passes = ceil_div(units, slots), busy = units < slots ? units : slots;
+    if (passes < best_pass || (passes == best_pass && busy > best_busy)) {
+      best = ks; best_pass = passes; best_busy = busy;
+    }
+  }
+  return best;
+}
+
+template <int WD, int PRO, int EPI, int KS>
+static int launch_gemv_ks(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s, int num_cu) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
   const size_t lds = gemv_lds_bytes(M, w.K);
-  auto kern = gemv_kernel<WD, PRO, EPI>;
+  auto kern = gemv_kernel<WD, PRO, EPI, KS>;
   static bool attr_set = false;  // per instantiation
+  static int wg_per_cu = 1;
   if (!attr_set) {
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
-  const int grid = min(NT, 256 * wg_per_cu);
+  // the grid is one resident wave of work-groups, each walking its share of the row-tiles
+  MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, kGemvWaves * 64, lds));
+  wg_per_cu = wg_per_cu < 1 ? 1 : (wg_per_cu > 2 ? 2 : wg_per_cu);
+  const int units = ceil_div(NT, kGemvWaves / KS);
+  int grid = min(units, num_cu * wg_per_cu);
+  // a work-group caches the scales of at most kGemvMaxTilesPerWg row-tiles
+  grid = max(grid, ceil_div(units * (kGemvWaves / KS), kGemvMaxTilesPerWg));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s,
                      reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K, p, e);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
 
+template <int WD, int PRO, int EPI>
+static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    MI_HIP(hipGetDevice(&dev));
+    MI_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  switch (gemv_pick_ks(w.N / 16, w.K / tile_k(WD), num_cu * 2)) {
+    case 1: return launch_gemv_ks<WD, PRO, EPI, 1>(w, M, p, e, s, num_cu);
+    case 2: return launch_gemv_ks<WD, PRO, EPI, 2>(w, M, p, e, s, num_cu);
+    case 4: return launch_gemv_ks<WD, PRO, EPI, 4>(w, M, p, e, s, num_cu);
+    default: return launch_gemv_ks<WD, PRO, EPI, 8>(w, M, p, e, s, num_cu);
+  }
+}
+
+// valid (prologue, epilogue) pairs: bf16 activations feed the row-parallel projections
+// (fp32 / residual out); the norm prologues feed QKV, gate|up and lm_head
 template <int WD>
 static int launch_gemv_wd(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
-  if (pro == PRO_NORM) {
+  if (pro == PRO_BF16) {
+    if (epi == EPI_RESID) return launch_gemv_t<WD, PRO_BF16, EPI_RESID>(w, M, p, e, s);
+    if (epi == EPI_F32) return launch_gemv_t<WD, PRO_BF16, EPI_F32>(w, M, p, e, s);
+  } else if (p.partial) {
+    if (epi == EPI_QKV) return launch_gemv_t<WD, PRO_NORM_PARTIAL, EPI_QKV>(w, M, p, e, s);
+    if (epi == EPI_SWIGLU) return launch_gemv_t<WD, PRO_NORM_PARTIAL, EPI_SWIGLU>(w, M, p, e, s);
+    if (epi == EPI_F32) return launch_gemv_t<WD, PRO_NORM_PARTIAL, EPI_F32>(w, M, p, e, s);
+  } else {
     if (epi == EPI_QKV) return launch_gemv_t<WD, PRO_NORM, EPI_QKV>(w, M, p, e, s);
     if (epi == EPI_SWIGLU) return launch_gemv_t<WD, PRO_NORM, EPI_SWIGLU>(w, M, p, e, s);
-    return launch_gemv_t<WD, PRO_NORM, EPI_F32>(w, M, p, e, s);
+    if (epi == EPI_F32) return launch_gemv_t<WD, PRO_NORM, EPI_F32>(w, M, p, e, s);
   }
-  if (epi == EPI_QKV) return launch_gemv_t<WD, PRO_BF16, EPI_QKV>(w, M, p, e, s);
-  if (epi == EPI_SWIGLU) return launch_gemv_t<WD, PRO_BF16, EPI_SWIGLU>(w, M, p, e, s);
-  return launch_gemv_t<WD, PRO_BF16, EPI_F32>(w, M, p, e, s);
+  set_error("gemv: unsupported prologue / epilogue combination");
+  return MI_EINVAL;
 }
 
 int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
@@ -392,6 +588,7 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
   if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_kernel<WD, EPI_QKV>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
   else if (epi == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<WD, EPI_SWIGLU>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
+  else if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_kernel<WD, EPI_RESID>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
   else hipLaunchKernelGGL((gemm_kernel<WD, EPI_F32>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
   MI_HIP(hipGetLastError());
   return MI_OK;

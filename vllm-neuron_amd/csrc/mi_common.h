@@ -116,6 +116,34 @@ __device__ __forceinline__ uint4 nt_load16(const uint4* p) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- weight stream primitives -----------------------------------------------------------
+// MI_STREAM_ASM = 0 (default): plain non-temporal loads; hipcc owns the s_waitcnt placement.
+//   It drains to vmcnt(0) once per pair of batches, so latency is hidden by wave-level
+//   parallelism (16 waves per CU), not by depth per wave.
+// MI_STREAM_ASM = 1: loads issued from inline asm and retired by hand-counted waits
+//   (cdna_hip_programming.md 5.7).  Measured hazard on hipcc 7.2: whenever an in-flight buffer is
+//   live across a control-flow merge the register allocator resolves the phi with v_mov copies
+//   of registers whose loads have not landed.  csrc/audit_stream.py detects exactly that in the
+//   emitted ISA; the build refuses such a library.  Kept for experiments only.
+#ifndef MI_STREAM_ASM
+#define MI_STREAM_ASM 0
+#endif
+#if MI_STREAM_ASM
+__device__ __forceinline__ void stream_load16(u32x4_t& dst, const uint4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off nt ; stream_load" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void stream_wait(u32x4_t& r) {
+  asm volatile("s_waitcnt vmcnt(%1) ; stream_release %0" : "+v"(r) : "n"(N) : "memory");
+}
+#else
+__device__ __forceinline__ void stream_load16(u32x4_t& dst, const uint4* p) {
+  dst = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+}
+template <int N>
+__device__ __forceinline__ void stream_wait(u32x4_t&) {}
+#endif
+
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // weight tile geometry: a tile is 16 rows x TILE_K(wd) columns = 1 KiB, lane l owns

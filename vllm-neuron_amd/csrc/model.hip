@@ -241,37 +241,55 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
                                  c->nkv_l, c->hd, c->attn_out, s));
     }
-    {  // O projection -> fp32 partial
+    const bool tp = k.tp_degree > 1;
+    {  // O projection.  TP = 1: straight into the residual stream (resid' = resid + y);
+       // TP > 1: fp32 partial -> RCCL all-reduce -> folded in by the next norm prologue.
       ProArgs p{};
       p.x = c->attn_out; p.ldx = c->q_dim;
       EpiArgs e{};
-      e.out_f32 = c->partial; e.ld_out = c->H;
-      MI_TRY(run_linear(c, W.o, rows, PRO_BF16, p, EPI_F32, e));
-      MI_TRY(all_reduce_partial(c, rows));
+      e.ld_out = c->H;
+      if (tp) {
+        e.out_f32 = c->partial;
+        MI_TRY(run_linear(c, W.o, rows, PRO_BF16, p, EPI_F32, e));
+        MI_TRY(all_reduce_partial(c, rows));
+      } else {
+        e.out_f32 = c->resid[cur ^ 1]; e.resid_in = c->resid[cur];
+        MI_TRY(run_linear(c, W.o, rows, PRO_BF16, p, EPI_RESID, e));
+        cur ^= 1;
+      }
     }
-    {  // residual + norm -> gate|up -> SwiGLU
+    {  // (residual +) norm -> gate|up -> SwiGLU
       ProArgs p{};
-      p.resid_in = c->resid[cur]; p.partial = c->partial; p.resid_out = c->resid[cur ^ 1];
+      p.resid_in = c->resid[cur];
+      p.partial = tp ? c->partial : nullptr;
+      p.resid_out = tp ? c->resid[cur ^ 1] : nullptr;
       p.gain = W.g_post; p.eps = k.rms_norm_eps;
       EpiArgs e{};
       e.act_out = c->act; e.ld_act = c->I_l;
       MI_TRY(run_linear(c, W.gu, rows, PRO_NORM, p, EPI_SWIGLU, e));
-      cur ^= 1;
+      if (tp) cur ^= 1;
     }
-    {  // down projection -> fp32 partial
+    {  // down projection
       ProArgs p{};
       p.x = c->act; p.ldx = c->I_l;
       EpiArgs e{};
-      e.out_f32 = c->partial; e.ld_out = c->H;
-      MI_TRY(run_linear(c, W.down, rows, PRO_BF16, p, EPI_F32, e));
-      MI_TRY(all_reduce_partial(c, rows));
+      e.ld_out = c->H;
+      if (tp) {
+        e.out_f32 = c->partial;
+        MI_TRY(run_linear(c, W.down, rows, PRO_BF16, p, EPI_F32, e));
+        MI_TRY(all_reduce_partial(c, rows));
+        have_partial = true;
+      } else {
+        e.out_f32 = c->resid[cur ^ 1]; e.resid_in = c->resid[cur];
+        MI_TRY(run_linear(c, W.down, rows, PRO_BF16, p, EPI_RESID, e));
+        cur ^= 1;
+      }
     }
-    have_partial = true;
   }
   {  // final norm + lm_head on the rows that are sampled (loader.py:363: logits[:, -1, :])
     ProArgs p{};
     p.resid_in = c->resid[cur] + (size_t)logits_row0 * c->H;
-    p.partial = c->partial + (size_t)logits_row0 * c->H;
+    p.partial = have_partial ? c->partial + (size_t)logits_row0 * c->H : nullptr;
     p.resid_out = nullptr;
     p.gain = c->g_final; p.eps = k.rms_norm_eps;
     EpiArgs e{};
