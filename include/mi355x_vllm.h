@@ -93,6 +93,10 @@ int mi_load_weight(mi_ctx* ctx, const char* name, const void* host, int32_t dtyp
 /* Bench/smoke only: N(0, std) matrices from a counter-based RNG in LOGICAL coordinates
  * (identical values whatever the sharding); norm gains 1. */
 int mi_init_synthetic_weights(mi_ctx* ctx, uint64_t seed, float std);
+/* Re-size the KV pool before mi_finalize: vLLM decides the block count after the weights
+ * are resident (worker.determine_available_memory -> KVCacheConfig.num_blocks; the reference's
+ * NxDI takes it at compile time as pa_num_blocks, loader.py:775-776). */
+int mi_set_num_blocks(mi_ctx* ctx, int32_t num_blocks);
 int mi_finalize(mi_ctx* ctx);
 
 /* One model call.  Host arrays, caller-owned, int64 like the reference's CPU tensors:

@@ -1,0 +1,472 @@
+"""Drop-in boundary behaviour on CPU (no GPU, no vLLM): registration, platform config
+rewrites, scheduler policy, loader config math, runner bookkeeping.  The scenarios and the
+known-answer tables are the ones the reference's own unit tests pin
+(/root/reference/test/unit/: test_init.py, test_platform.py, core/test_scheduler.py,
+worker/test_model_loader.py, worker/test_model_runner.py — cited per test)."""
+
+import warnings
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import vllm_neuron_amd
+from vllm_neuron_amd import platform as plat
+from vllm_neuron_amd._vllm_compat import (CachedRequestData, KVCacheConfig, NewRequestData, Request,
+                                          RequestStatus, SamplerOutput, SamplingParams,
+                                          SchedulerOutput, SimpleCacheConfig, SimpleModelConfig,
+                                          SimpleParallelConfig, SimpleSchedulerConfig, SimpleVllmConfig)
+from vllm_neuron_amd.core.scheduler import (ContinuousBatchingMI355XScheduler,
+                                            check_stop_with_min_tokens)
+from vllm_neuron_amd.worker import mi355x_model_loader as loader
+from vllm_neuron_amd.worker.mi355x_model_runner import MI355XModelRunner
+
+
+def hf_cfg(**kw):
+    base = dict(architectures=["LlamaForCausalLM"], num_key_value_heads=2, head_dim=64, vocab_size=512,
+                num_attention_heads=8, hidden_size=256, num_hidden_layers=2, intermediate_size=512,
+                rms_norm_eps=1e-5, rope_theta=10000.0, model_type="llama")
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def vcfg(max_model_len=256, max_num_seqs=4, block_size=32, prefix=True, override=None, tp=1, **kw):
+    return SimpleVllmConfig(
+        model_config=SimpleModelConfig(model="m", hf_config=hf_cfg(), dtype="bfloat16", max_model_len=max_model_len),
+        cache_config=SimpleCacheConfig(block_size=block_size, num_gpu_blocks_override=override,
+                                       enable_prefix_caching=prefix),
+        parallel_config=SimpleParallelConfig(tensor_parallel_size=tp),
+        scheduler_config=SimpleSchedulerConfig(max_num_seqs=max_num_seqs, max_model_len=max_model_len), **kw)
+
+
+# ---- registration (reference test/unit/test_init.py:9-41) -----------------------------------
+def test_register_without_device(monkeypatch):
+    monkeypatch.setattr(vllm_neuron_amd, "_is_mi355x_dev", lambda: False)
+    with pytest.warns(UserWarning, match="Skipping MI355X plugin registration"):
+        assert vllm_neuron_amd.register() is None
+
+
+def test_register_with_device(monkeypatch):
+    monkeypatch.setattr(vllm_neuron_amd, "_is_mi355x_dev", lambda: True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert vllm_neuron_amd.register() == "vllm_neuron_amd.platform.MI355XPlatform"
+    mod, cls = vllm_neuron_amd.register().rsplit(".", 1)
+    assert getattr(__import__(mod, fromlist=[cls]), cls) is plat.MI355XPlatform
+
+
+# ---- platform (reference test/unit/test_platform.py) ------------------------------------------
+def test_platform_attrs():                                      # :20-36
+    p = plat.MI355XPlatform()
+    assert p.device_type == "cpu" and p.device_name == "cpu"
+    assert p.is_out_of_tree() if hasattr(p, "is_out_of_tree") else True
+    assert "fbgemm_fp8" in p.supported_quantization and "mi355x_quant" in p.supported_quantization
+    assert p.get_device_name() == "mi355x"
+    assert p.is_async_output_supported(None) is False
+    assert p.is_pin_memory_available() is False and p.use_all_gather() is True
+    assert p.supports_v1(None) is True
+
+
+def test_worker_and_scheduler_cls_rewrite():                    # :156-195
+    c = vcfg()
+    plat.MI355XPlatform.check_and_update_config(c)
+    assert c.parallel_config.worker_cls == plat.WORKER_CLS
+    assert c.scheduler_config.scheduler_cls == plat.SCHEDULER_CLS
+    assert c.scheduler_config.chunked_prefill_enabled is False
+    assert c.scheduler_config.max_num_batched_tokens == 131072        # :531-549
+    c2 = vcfg()
+    c2.parallel_config.worker_cls = "my.Worker"
+    plat.MI355XPlatform.check_and_update_config(c2)
+    assert c2.parallel_config.worker_cls == "my.Worker"
+
+
+def test_block_size_and_null_block():                           # :198-222, :673-762
+    c = vcfg(max_model_len=2048, prefix=False, block_size=None, override=1)
+    plat.MI355XPlatform.check_and_update_config(c)
+    assert c.cache_config.block_size == 2048
+    assert c.cache_config.num_gpu_blocks_override == 2
+    plat.MI355XPlatform.check_and_update_config(c)               # idempotent per CacheConfig instance
+    assert c.cache_config.num_gpu_blocks_override == 2
+    c.cache_config = SimpleCacheConfig(block_size=32, num_gpu_blocks_override=5, enable_prefix_caching=True)
+    plat.MI355XPlatform.check_and_update_config(c)               # a NEW CacheConfig is adjusted again
+    assert c.cache_config.num_gpu_blocks_override == 6
+    assert c.cache_config.block_size == 32
+
+
+def test_uni_executor_and_defaults():                           # :225-248, :531-549
+    c = vcfg(tp=8, max_num_seqs=None)
+    plat.MI355XPlatform.check_and_update_config(c)
+    assert c.parallel_config.distributed_executor_backend == "uni"
+    assert c.scheduler_config.max_num_seqs == 32
+
+
+def test_missing_block_size_asserts(monkeypatch):               # :280-306, :414-428
+    c = vcfg(block_size=None, prefix=True)
+    with pytest.raises(AssertionError, match="block_size must be set"):
+        plat.MI355XPlatform.check_and_update_config(c)
+    monkeypatch.setenv("DISABLE_MI355X_CUSTOM_SCHEDULER", "1")
+    c = vcfg(block_size=None)
+    with pytest.raises(AssertionError, match="block_size must be set"):
+        plat.MI355XPlatform.check_and_update_config(c)
+
+
+def test_empty_vllm_config_is_tolerated():                      # platform.py:142-144
+    c = vcfg()
+    c.model_config = None
+    plat.MI355XPlatform.check_and_update_config(c)
+    assert c.parallel_config.worker_cls == "auto"
+
+
+# ---- scheduler (reference test/unit/core/test_scheduler.py) -----------------------------------
+def make_sched(max_num_seqs=4, num_blocks=64):
+    c = vcfg(max_num_seqs=max_num_seqs)
+    plat.MI355XPlatform.check_and_update_config(c)
+    return ContinuousBatchingMI355XScheduler(c, KVCacheConfig(num_blocks=num_blocks))
+
+
+def req(i, n=5, **sp):
+    return Request(f"r{i}", list(range(1, n + 1)), SamplingParams(temperature=0.0, **{"max_tokens": 8, **sp}),
+                   eos_token_id=2)
+
+
+def fake_output(sched_out, tok=7):
+    ids = [r.req_id for r in sched_out.scheduled_new_reqs] + list(sched_out.scheduled_cached_reqs.req_ids)
+    return SimpleNamespace(req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
+                           sampled_token_ids=[[tok] for _ in ids])
+
+
+def test_one_prompt_per_step_then_decode():                     # :404-422, :382-402
+    s = make_sched()
+    for i in range(3):
+        s.add_request(req(i))
+    seen = []
+    for _ in range(3):
+        out = s.schedule()
+        assert len(out.scheduled_new_reqs) == 1 and not out.scheduled_cached_reqs.req_ids   # prefill XOR decode
+        assert len(s.holdback_queue) == 0
+        seen.append(out.scheduled_new_reqs[0].req_id)
+        s.update_from_output(out, fake_output(out))
+    assert seen == ["r0", "r1", "r2"]
+    out = s.schedule()
+    assert not out.scheduled_new_reqs and sorted(out.scheduled_cached_reqs.req_ids) == ["r0", "r1", "r2"]
+
+
+def test_capacity_limit():                                      # :147-164
+    s = make_sched(max_num_seqs=2)
+    for i in range(3):
+        s.add_request(req(i))
+    for _ in range(2):
+        out = s.schedule()
+        s.update_from_output(out, fake_output(out))
+    out = s.schedule()                                           # batch is full: r2 stays waiting, decode runs
+    assert not out.scheduled_new_reqs and len(out.scheduled_cached_reqs.req_ids) == 2
+    assert [r.request_id for r in s.waiting] == ["r2"]
+
+
+def test_min_tokens_beats_eos_and_stop_tokens():                # :256-365
+    r = req(0, min_tokens=3, stop_token_ids=[9])
+    r.append_output_token_ids(2)                                 # EOS as first token
+    assert check_stop_with_min_tokens(r, 100) is False
+    r.append_output_token_ids(9)
+    assert check_stop_with_min_tokens(r, 100) is False
+    r.append_output_token_ids(9)
+    assert check_stop_with_min_tokens(r, 100) is True and r.status == RequestStatus.FINISHED_STOPPED
+    assert r.stop_reason == 9
+    r2 = req(1)
+    r2.append_output_token_ids(2)
+    assert check_stop_with_min_tokens(r2, 100) is True
+    r3 = req(2, ignore_eos=True)
+    r3.append_output_token_ids(2)
+    assert check_stop_with_min_tokens(r3, 100) is False
+
+
+def test_length_cap():                                          # :424-444
+    r = req(0, max_tokens=2)
+    r.append_output_token_ids(5)
+    assert check_stop_with_min_tokens(r, 100) is False
+    r.append_output_token_ids(5)
+    assert check_stop_with_min_tokens(r, 100) is True and r.status == RequestStatus.FINISHED_LENGTH_CAPPED
+    r = req(1, n=9, max_tokens=50)
+    r.append_output_token_ids(5)
+    assert check_stop_with_min_tokens(r, 10) is True             # num_tokens >= max_model_len
+
+
+def test_scheduler_stop_trims_tokens():
+    s = make_sched()
+    s.add_request(req(0, max_tokens=1))
+    out = s.schedule()
+    outs = s.update_from_output(out, fake_output(out))
+    assert outs[0].finished and outs[0].new_token_ids == [7]
+    assert not s.has_unfinished_requests()
+    assert "r0" in s.schedule().finished_req_ids
+
+
+# ---- loader config math (reference test/unit/worker/test_model_loader.py) -----------------------
+def loader_cfgs(max_model_len=256, max_num_seqs=4, block_size=32, override=None, prefix=True):
+    c = vcfg(max_model_len, max_num_seqs, block_size, prefix, override)
+    return c.model_config, c.cache_config, c.parallel_config, c.scheduler_config
+
+
+def test_default_config_fields():                               # :535-588
+    m, cache, par, sch = loader_cfgs()
+    d = loader._get_default_mi355x_config(m, cache, par, sch, None, None)
+    assert d["tp_degree"] == 1 and d["ctx_batch_size"] == 1 and d["batch_size"] == 4
+    assert d["max_context_length"] == 256 and d["seq_len"] == 256 and d["enable_bucketing"] is True
+    assert d["is_continuous_batching"] is True and d["quantized"] is False and d["torch_dtype"] == "bfloat16"
+    assert d["padding_side"] == "right" and d["pa_block_size"] == 32
+    assert d["pa_num_blocks"] == (256 // 32) * 4
+    assert d["is_block_kv_layout"] is True and d["is_prefix_caching"] is True
+    assert d["on_device_sampling_config"] is None               # CPU sampling is the implemented path
+
+
+@pytest.mark.parametrize("max_model_len,max_num_seqs,block_size,is_block,pa_num_blocks,ok", [
+    (2048, 32, 16, True, 2000, False), (1024, 16, 8, True, 3000, True), (512, 8, 4, True, 1024, True),
+    (1000, 10, 16, True, 630, True), (1000, 10, 16, True, 620, False), (4096, 64, 8, False, 100, True)])
+def test_sufficient_blocks_validation(max_model_len, max_num_seqs, block_size, is_block, pa_num_blocks, ok):
+    """Known-answer table of reference test_model_loader.py:2831-2842 (min blocks use ceil)."""
+    _, cache, _, sch = loader_cfgs(max_model_len, max_num_seqs, block_size, prefix=False)
+    cfg = {"is_block_kv_layout": is_block, "pa_num_blocks": pa_num_blocks}
+    if ok:
+        assert loader._validate_mi355x_config(cache, sch, cfg) is cfg
+    else:
+        with pytest.raises(AssertionError, match="blocks are required"):
+            loader._validate_mi355x_config(cache, sch, cfg)
+
+
+@pytest.mark.parametrize("override,pa_num_blocks,matching,sufficient", [
+    (201, None, True, True), (200, None, True, False), (201, 200, True, True), (200, 199, True, False),
+    (201, 150, False, None), (201, 201, False, None), (None, 200, False, None)])
+def test_pa_num_blocks_matrix(override, pa_num_blocks, matching, sufficient):
+    """Known-answer matrix of reference test_model_loader.py:2915-2949: exactly 200 blocks are
+    required (max_model_len 1600 / block_size 8, one sequence)."""
+    m, cache, par, sch = loader_cfgs(1600, 1, 8, override)
+    ov = {"is_block_kv_layout": True}
+    if pa_num_blocks is not None:
+        ov["pa_num_blocks"] = pa_num_blocks
+
+    def run():
+        cfg = loader._get_mi355x_config_after_override(
+            loader._get_default_mi355x_config(m, cache, par, sch, None, None), dict(ov))
+        cfg = loader._handle_pa_num_blocks(cache, cfg, ov)
+        return loader._validate_mi355x_config(cache, sch, cfg)
+
+    if matching and sufficient:
+        assert run()["pa_num_blocks"] == override
+    elif not matching:
+        with pytest.raises(ValueError, match="pa_num_blocks"):
+            run()
+    else:
+        with pytest.raises(AssertionError):
+            run()
+
+
+def test_override_merge_and_quant_keys():                       # loader.py:870-900
+    d = {"batch_size": 4, "quantized": False}
+    out = loader._get_mi355x_config_after_override(d, {"quantized": True, "skip_warmup": True,
+                                                      "text_neuron_config": {}, "vision_neuron_config": {}})
+    assert out["quantized"] is True and out["quantization_dtype"] == "int8"
+    assert out["quantization_type"] == "per_tensor_symmetric" and out["quantized_checkpoints_path"] is None
+    assert out["skip_warmup"] is True and "text_neuron_config" not in out and "vision_neuron_config" not in out
+    out = loader._get_mi355x_config_after_override({"a": 1}, {"quantized": True, "quantization_dtype": "f8e4m3",
+                                                            "quantization_type": "per_channel_symmetric"})
+    assert out["quantization_dtype"] == "f8e4m3" and out["quantization_type"] == "per_channel_symmetric"
+    assert loader._get_mi355x_config_after_override({"a": 1}, None) == {"a": 1}
+
+
+def test_get_model_configs_errors():                            # loader.py:612-631
+    assert loader._get_model_configs(hf_cfg()) == ("LlamaForCausalLM", 2, 64)
+    assert loader._get_model_configs(hf_cfg(head_dim=None)) == ("LlamaForCausalLM", 2, 32)
+    with pytest.raises(ValueError, match="No architectures"):
+        loader._get_model_configs(hf_cfg(architectures=[]))
+    with pytest.raises(ValueError, match="Missing required fields"):
+        loader._get_model_configs(hf_cfg(num_key_value_heads=None))
+    with pytest.raises(ValueError, match="is not supported on MI355X"):
+        loader._check_architecture("GPT2LMHeadModel")
+
+
+def test_override_key_alias():
+    assert loader.get_override_config({"override_neuron_config": {"a": 1}}) == {"a": 1}
+    assert loader.get_override_config({"override_mi355x_config": {"b": 2}, "override_neuron_config": {"a": 1}}) == {"b": 2}
+    assert loader.get_override_config({}) is None and loader.get_override_config(None) is None
+
+
+def test_sort_inputs_and_reordered():                           # :1245-1274, :1334-1356, :1656-1681
+    base = loader.MI355XModelBase(hf_cfg())
+    ids = torch.tensor([2, 0, 1])
+    inputs = dict(input_ids=torch.tensor([[20], [0], [10]]), names=["c", "a", "b"], empty=torch.tensor([]),
+                  other=torch.zeros(5, 1), scalar=3)
+    base.is_reorder_needed = True
+    with base._reordered(ids, **inputs) as (sorted_ids, srt, restore):
+        assert sorted_ids.tolist() == [0, 1, 2]
+        assert srt["input_ids"].flatten().tolist() == [0, 10, 20] and srt["names"] == ["a", "b", "c"]
+        assert srt["empty"].numel() == 0 and srt["other"].shape == (5, 1) and srt["scalar"] == 3
+        assert restore(srt["input_ids"]).flatten().tolist() == [20, 0, 10]
+    base.is_reorder_needed = False
+    with base._reordered(ids, **inputs) as (same_ids, same, restore):
+        assert same_ids is ids and same["input_ids"] is inputs["input_ids"]
+        assert restore(inputs["input_ids"]) is inputs["input_ids"]
+
+
+# ---- runner bookkeeping (reference test/unit/worker/test_model_runner.py) ------------------------
+class FakeModel:
+    """Stands in for MI355XCausalLM: records the kwargs, returns logits that make token
+    (10 + row) the argmax."""
+
+    def __init__(self, vocab=512, prefix=True):
+        self.mi355x_config = loader.MI355XConfig(
+            is_block_kv_layout=prefix, is_prefix_caching=prefix, chunked_prefill_config=None,
+            on_device_sampling_config=None, attn_tkg_nki_kernel_enabled=False,
+            attn_block_tkg_nki_kernel_enabled=False)
+        self.num_key_value_heads, self.head_dim, self.vocab = 2, 64, vocab
+        self.calls = []
+        self.is_reorder_needed = False
+        self.model = SimpleNamespace(finalize=lambda: None, set_num_blocks=lambda n: None)
+
+    def __call__(self, **kw):
+        self.calls.append(kw)
+        B = kw["input_ids"].shape[0]
+        logits = torch.zeros(B, self.vocab)
+        logits[torch.arange(B), 10 + torch.arange(B)] = 5.0
+        return logits
+
+    def sample(self, logits):
+        raise RuntimeError("not used")
+
+
+def make_runner(prefix=True, **kw):
+    c = vcfg(prefix=prefix, **kw)
+    plat.MI355XPlatform.check_and_update_config(c)
+    r = MI355XModelRunner(c, "cpu")
+    r.model = FakeModel(prefix=prefix)
+    r.is_block_kv_layout = r.is_prefix_caching = prefix
+    r._kv_ready = True
+    return r
+
+
+def sched_out(new=(), cached=None, finished=()):
+    cached = cached or CachedRequestData()
+    nst = {n.req_id: len(n.prompt_token_ids) - n.num_computed_tokens for n in new}
+    nst.update({r: 1 for r in cached.req_ids})
+    return SchedulerOutput(scheduled_new_reqs=list(new), scheduled_cached_reqs=cached, num_scheduled_tokens=nst,
+                           total_num_scheduled_tokens=sum(nst.values()), finished_req_ids=set(finished))
+
+
+def new_req(rid, prompt, blocks, computed=0, **sp):
+    return NewRequestData(req_id=rid, prompt_token_ids=prompt, mm_features=[],
+                          sampling_params=SamplingParams(temperature=0.0, **sp), pooling_params=None,
+                          block_ids=(list(blocks),), num_computed_tokens=computed)
+
+
+def test_prefill_input_contract_with_prefix_hit():              # reference runner.py:704-763, 853-885
+    from tests.helpers import prefill_inputs
+    r = make_runner()
+    prompt = list(range(100, 170))
+    out = r.execute_model(sched_out([new_req("a", prompt, [3, 9, 4], computed=64)]))
+    kw = r.model.calls[0]
+    want = prefill_inputs(prompt, [3, 9, 4], 32, 256, 64)
+    assert torch.equal(kw["input_ids"], want["input_ids"]) and torch.equal(kw["position_ids"], want["position_ids"])
+    assert torch.equal(kw["block_tables"], want["block_table"])
+    assert torch.equal(kw["slot_mapping"], want["slot_mapping"])
+    assert kw["full_context_lens"].tolist() == [[70]] and kw["computed_context_lens"].tolist() == [[64]]
+    assert kw["input_block_ids"].tolist() == [r.vllm_req_to_seq_id_mapping["a"]]
+    assert out.sampled_token_ids == [[10]] and out.req_ids == ["a"]
+    assert r.requests["a"].output_token_ids == [10]
+
+
+def test_decode_input_contract_and_block_append():              # runner.py:765-832; tests :821-872
+    from tests.helpers import decode_inputs
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", list(range(31)), [5])]))
+    r.execute_model(sched_out([new_req("b", list(range(40)), [6, 7])]))
+    cached = CachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[False, False], new_token_ids=[[], []],
+                               new_block_ids=[([8],), None], num_computed_tokens=[31, 40])
+    out = r.execute_model(sched_out(cached=cached))
+    kw = r.model.calls[-1]
+    want = decode_inputs([10, 10], [31, 40], [[5, 8], [6, 7]], 32, 256)
+    for k_mine, k_ref in (("input_ids", "input_ids"), ("position_ids", "position_ids"),
+                          ("block_tables", "block_table"), ("slot_mapping", "slot_mapping"),
+                          ("full_context_lens", "full_context_lens"),
+                          ("computed_context_lens", "computed_context_lens")):
+        assert torch.equal(kw[k_mine], want[k_ref]), k_mine
+    assert r.requests["a"].block_ids == ([5, 8],)                 # appended, not replaced
+    # rows come back in model order (a, b) and are re-ordered to the persistent batch's order
+    got = {rid: out.sampled_token_ids[out.req_id_to_index[rid]] for rid in out.req_ids}
+    assert got == {"a": [10], "b": [11]}
+    # resumed from preemption: block ids are REPLACED (tests :984-1018)
+    cached = CachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[True, False], new_token_ids=[[], []],
+                               new_block_ids=[([20, 21],), None], num_computed_tokens=[32, 41])
+    r.execute_model(sched_out(cached=cached))
+    assert r.requests["a"].block_ids == ([20, 21],)
+
+
+def test_finished_requests_free_seq_ids():                      # tests :683-718, :1020-1049
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    slot = r.vllm_req_to_seq_id_mapping["a"]
+    assert slot not in r.free_seq_ids
+    out = r.execute_model(sched_out(finished=["a"]))
+    assert out.sampled_token_ids == [] and slot in r.free_seq_ids
+    assert "a" not in r.requests and "a" not in r.vllm_req_to_seq_id_mapping
+    assert r.input_batch.req_ids == []
+
+
+def test_minus_one_pads_are_stripped():                         # tests :773-819, :922-956
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    r.execute_model(sched_out([new_req("b", [1, 2], [2])]))
+    cached = CachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[False, False], new_token_ids=[[], []],
+                               new_block_ids=[None, None], num_computed_tokens=[3, 2])
+    r.execute_model(sched_out(cached=cached))                    # both requests are in the batch again
+    first = r.input_batch.req_ids[0]
+    n_before = len(r.requests[first].output_token_ids)
+    out = r._generate_model_runner_output(SamplerOutput(sampled_token_ids=torch.tensor([[0], [-1]])))
+    assert out.sampled_token_ids == [[0], []]                    # 0 is a token, -1 a pad
+    assert r.requests[first].output_token_ids[-1] == 0 and len(r.requests[first].output_token_ids) == n_before + 1
+    assert r._generate_model_runner_output(None).sampled_token_ids == []
+
+
+def test_greedy_sampling_params_rewrite():                      # tests :1373-1418
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    r.requests["a"].sampling_params = SamplingParams(temperature=0.0, top_k=50, top_p=0.9)
+    p = r.get_mi355x_sampling_params(torch.zeros(1, 1))
+    assert p.shape == (1, 3) and p[0].tolist() == pytest.approx([1.0, 0.9, 1.0])
+    r.requests["a"].sampling_params = SamplingParams(temperature=0.7, top_k=0, top_p=1.0)
+    assert r.get_mi355x_sampling_params(torch.zeros(1, 1))[0].tolist() == pytest.approx([256.0, 1.0, 0.7])
+
+
+def test_cpu_sampling_validation_errors():                      # reference test_cpu_sampling.py:99-118, 253-276
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    mi = SimpleNamespace(request_ids=["a"])
+    with pytest.raises(RuntimeError, match="CPU sampling failed.*2D tensor"):
+        r._cpu_sample(torch.zeros(1, 1, 512), mi)
+    with pytest.raises(RuntimeError, match="does not match model vocab size"):
+        r._cpu_sample(torch.zeros(1, 100), mi)
+    calls = []
+    r.cpu_sampler = lambda logits, md: calls.append((logits, md)) or SamplerOutput(torch.tensor([[3]]))
+    assert r._cpu_sample(torch.zeros(1, 512), mi).sampled_token_ids.tolist() == [[3]]
+    assert len(calls) == 1 and calls[0][1] is r.input_batch.sampling_metadata
+
+
+def test_contiguous_kv_mode_inputs():
+    """Prefix caching off: block_size = max_model_len, no slot / block tensors (runner.py:715-724)."""
+    r = make_runner(prefix=False, block_size=None)
+    assert r.block_size == 256
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    kw = r.model.calls[0]
+    assert kw["block_tables"].numel() == 0 and kw["slot_mapping"].numel() == 0
+    assert kw["full_context_lens"].tolist() == [[3]]
+    spec = r.get_kv_cache_spec()["layer"]
+    assert (spec.block_size, spec.num_kv_heads, spec.head_size, spec.dtype) == (256, 2, 64, torch.bfloat16)
+
+
+def test_unsupported_features_raise():
+    r = make_runner()
+    with pytest.raises(NotImplementedError):
+        r.execute_model(sched_out([NewRequestData("m", [1], ["img"], SamplingParams(), None, ([1],), 0)]))
+    c = vcfg()
+    c.lora_config = object()
+    rr = MI355XModelRunner(c, "cpu")
+    with pytest.raises(NotImplementedError, match="Multi-lora"):
+        rr.load_model()

@@ -54,6 +54,7 @@ _SIGS = {
     "mi_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32,
                                  C.POINTER(C.c_int64), C.c_int32]),
     "mi_init_synthetic_weights": (C.c_int, [C.c_void_p, C.c_uint64, C.c_float]),
+    "mi_set_num_blocks": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi_finalize": (C.c_int, [C.c_void_p]),
     "mi_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -176,6 +177,10 @@ class NativeModel:
     def tp_init(self, uid: bytes) -> None:
         assert len(uid) == 128
         check(self.lib.mi_tp_init(self._ctx, C.create_string_buffer(uid, 128)))
+
+    def set_num_blocks(self, num_blocks: int) -> None:
+        check(self.lib.mi_set_num_blocks(self._ctx, num_blocks))
+        self.cfg.num_blocks = num_blocks
 
     def finalize(self) -> None:
         check(self.lib.mi_finalize(self._ctx))

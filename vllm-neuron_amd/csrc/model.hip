@@ -625,6 +625,13 @@ int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
   return MI_OK;
 }
 
+int mi_set_num_blocks(mi_ctx* c, int32_t num_blocks) {
+  MI_CHECK(c && !c->finalized, "mi_set_num_blocks after mi_finalize");
+  MI_CHECK(num_blocks >= 2, "num_blocks must include the null block and at least one real block");
+  c->cfg.num_blocks = num_blocks;
+  return MI_OK;
+}
+
 int mi_finalize(mi_ctx* c) {
   MI_CHECK(c && !c->finalized, "bad state");
   MI_CHECK(c->have_lm_head, "lm_head.weight (or tied embed_tokens) was never loaded");

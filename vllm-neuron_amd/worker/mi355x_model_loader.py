@@ -1,0 +1,406 @@
+# SPDX-License-Identifier: Apache-2.0
+"""Model adapter + config derivation for the MI355X backend.
+
+Mirror of the reference's loader
+(/root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py): the same config
+dictionary (keys, defaults, override merge, ``pa_num_blocks`` <-> ``num_gpu_blocks_override``
+reconciliation, validation errors) and the same adapter surface (``forward`` returning the
+last-token logits for the CPU-sampling path, ``sample``, ``load_weights``), but the object
+behind it is a ``NativeModel`` (libmi355x_vllm.so) instead of an NxDI model.
+
+Override channel: ``vllm_config.additional_config["override_mi355x_config"]`` (the reference's
+``"override_neuron_config"`` key is accepted as an alias so existing launch scripts keep
+working).  Extra keys understood here:
+  context_encoding_buckets   list[int]      workspace / graph buckets (README.md:80 semantics)
+  synthetic_weights          {"seed","std"} random weights generated on the device (bench)
+  state_dict                 dict[str, Tensor] in-memory HF-named weights (tests)
+  use_graphs                 bool           hipGraph capture of token-generation steps
+"""
+
+from __future__ import annotations
+
+import glob
+import logging
+import os
+from contextlib import contextmanager
+from math import ceil
+from types import SimpleNamespace
+from typing import Any
+
+import torch
+import torch.nn as nn
+
+from .._vllm_compat import SamplerOutput
+from .constants import (MI355X_MULTI_MODAL_MODELS, SUPPORTED_ARCHITECTURES,
+                        TORCH_DTYPE_TO_MI355X_AMP)
+
+logger = logging.getLogger(__name__)
+
+OVERRIDE_KEYS = ("override_mi355x_config", "override_neuron_config")
+_QUANT_DTYPES = {"int8": 2, "f8e4m3": 1, "fp8": 1, "float8_e4m3fn": 1}
+_QUANT_TYPES = {"per_tensor_symmetric": 0, "per_channel_symmetric": 1}
+
+
+class MI355XConfig(SimpleNamespace):
+    """Attribute view of the merged config dict (plays the role of NxDI's NeuronConfig)."""
+
+    def get(self, key, default=None):
+        return getattr(self, key, default)
+
+
+class MI355XModelBase(nn.Module):
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.hf_config = config
+        self.model = None                    # NativeModel, set by load_weights
+        self.mi355x_config: MI355XConfig | None = None
+        self.is_reorder_needed: bool = False
+        self.architecture: str = ""
+        self.num_key_value_heads: int = 0
+        self.head_dim: int = 0
+
+    # the reference exposes the merged config as `.neuron_config`; keep that spelling alive
+    @property
+    def neuron_config(self):
+        return self.mi355x_config
+
+    def forward(self, input_ids, positions, input_block_ids, sampling_params, **kwargs):
+        raise NotImplementedError
+
+    def sample(self, logits: torch.Tensor) -> SamplerOutput | None:
+        raise NotImplementedError
+
+    def load_weights(self, model_name_or_path: str, architecture: str, **kwargs):
+        raise NotImplementedError
+
+    @contextmanager
+    def _reordered(self, input_block_ids: torch.Tensor, **inputs):
+        """Yield (seq ids, inputs, restore).  With contiguous KV the reference must present
+        sequences in seq-id order (loader.py:110-133); the block-table addressing used here
+        does not depend on row order, but the contract (sort, run, restore) is kept."""
+        if self.is_reorder_needed:
+            sorted_ids, sorted_indices = torch.sort(input_block_ids)
+            reordered = self._sort_inputs(inputs, sorted_indices)
+
+            def restore(output: torch.Tensor) -> torch.Tensor:
+                if sorted_ids.shape[0] != 1:
+                    return torch.index_select(output, 0, torch.argsort(sorted_indices))
+                return output
+
+            yield sorted_ids, reordered, restore
+        else:
+            yield input_block_ids, inputs, lambda x: x
+
+    @staticmethod
+    def _sort_inputs(inputs: dict[str, Any], sorted_indices: torch.Tensor) -> dict[str, Any]:
+        n = sorted_indices.shape[0]
+        out = {}
+        for key, val in inputs.items():
+            if isinstance(val, torch.Tensor) and val.shape[0] > 0 and val.shape[0] == n:
+                out[key] = torch.index_select(val, 0, sorted_indices)
+            elif isinstance(val, list):
+                out[key] = [val[i.item()] for i in sorted_indices]
+            else:
+                out[key] = val      # empty tensors, mismatched batch (prefill-only inputs), scalars
+        return out
+
+
+class MI355XCausalLM(MI355XModelBase):
+    """`forward` = one call of libmi355x_vllm's mi_forward (reference loader.py:336-365)."""
+
+    def forward(self, input_ids, input_block_ids, **kwargs):
+        cfg = self.mi355x_config
+        with self._reordered(input_block_ids, input_ids=input_ids, **kwargs) as (seq_ids, inputs, restore):
+            ids = inputs["input_ids"]
+            if cfg.on_device_sampling_config:
+                raise NotImplementedError("on-device sampling is not implemented on MI355X yet; "
+                                          "leave on_device_sampling_config unset (CPU sampling)")
+            if cfg.is_block_kv_layout:
+                block_table, slot_mapping = inputs["block_tables"], inputs["slot_mapping"]
+            else:
+                block_table, slot_mapping = self._batch_line_addressing(seq_ids, inputs["position_ids"],
+                                                                        inputs["full_context_lens"],
+                                                                        inputs.get("computed_context_lens"),
+                                                                        ids.shape[1])
+            computed = inputs.get("computed_context_lens")
+            if computed is None or computed.numel() == 0:
+                # contiguous KV: prefill computes everything, decode everything but the new token
+                full = inputs["full_context_lens"].reshape(-1)
+                computed = torch.zeros_like(full) if ids.shape[1] > 1 else full - 1
+            logits = self.model.forward(ids, inputs["position_ids"], seq_ids, block_table, slot_mapping,
+                                        inputs["full_context_lens"], computed)
+            return restore(logits)
+
+    def _batch_line_addressing(self, seq_ids, position_ids, full_context_lens, computed, S):
+        """Contiguous ('batch line') KV expressed through the block pool: sequence id s owns
+        block s + 1, whose size is the (padded) max_model_len."""
+        bs = self.native_block_size
+        B = seq_ids.shape[0]
+        block_table = (seq_ids.reshape(B, 1) + 1).to(torch.long)
+        full = full_context_lens.reshape(-1)
+        if S == 1:
+            pos = position_ids.reshape(B, 1)
+            slots = block_table * bs + pos
+        else:
+            ar = torch.arange(S, dtype=torch.long)[None, :].expand(B, S)
+            slots = torch.where(ar < full[:, None], block_table * bs + ar, torch.full_like(ar, -1))
+        return block_table, slots
+
+    def sample(self, logits: torch.Tensor) -> SamplerOutput | None:
+        if self.mi355x_config.on_device_sampling_config:
+            return SamplerOutput(sampled_token_ids=logits.unsqueeze(-1), logprobs_tensors=None)
+        raise RuntimeError("CPU sampling should be handled by the model runner, not the model. "
+                           "This indicates a bug in the sampling path routing.")
+
+    # ---- weights ------------------------------------------------------------------------
+    def load_weights(self, model_name_or_path: str, architecture: str, **kwargs):
+        from .._native import NativeModel
+        cfg: dict = kwargs["mi355x_config"]
+        hf = self.hf_config
+        geo = _decoder_geometry(hf)
+        max_model_len = cfg["seq_len"]
+        if cfg["is_block_kv_layout"]:
+            block_size, num_blocks = cfg["pa_block_size"], cfg["pa_num_blocks"]
+        else:
+            block_size = -(-max_model_len // 32) * 32
+            num_blocks = cfg["batch_size"] + 1
+        self.native_block_size = block_size
+        quantized = bool(cfg.get("quantized"))
+        if quantized and cfg.get("quantized_checkpoints_path"):
+            raise NotImplementedError("pre-quantized checkpoints are not supported yet: weights are "
+                                      "quantized at load (quantized_checkpoints_path must be unset)")
+        qdtype = cfg.get("quantization_dtype", "int8")
+        qtype = cfg.get("quantization_type", "per_tensor_symmetric")
+        if quantized and (qdtype not in _QUANT_DTYPES or qtype not in _QUANT_TYPES):
+            raise ValueError(f"unsupported quantization_dtype/type: {qdtype!r}/{qtype!r}")
+        not_converted = cfg.get("modules_to_not_convert") or []
+        tp_rank = int(kwargs.get("tp_rank", 0))
+        self.model = NativeModel(
+            num_blocks=int(num_blocks), block_size=int(block_size),
+            max_num_seqs=int(cfg["batch_size"]), max_model_len=int(max_model_len),
+            ctx_buckets=cfg.get("context_encoding_buckets") or [],
+            weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0,
+            quant_type=_QUANT_TYPES[qtype] if quantized else 0,
+            quantize_lm_head=int(quantized and not any("lm_head" in m for m in not_converted)),
+            tp_degree=int(cfg["tp_degree"]), tp_rank=tp_rank,
+            device_id=int(kwargs.get("device_id", 0)), use_graphs=int(cfg.get("use_graphs", True)),
+            **geo)
+        if cfg["tp_degree"] > 1:
+            uid = kwargs.get("tp_unique_id")
+            if uid is None:
+                raise RuntimeError("tp_degree > 1 needs the RCCL unique id broadcast by the worker")
+            self.model.tp_init(uid)
+        synthetic = cfg.get("synthetic_weights")
+        state_dict = cfg.get("state_dict")
+        if synthetic is not None:
+            self.model.init_synthetic_weights(int(synthetic.get("seed", 1)), float(synthetic.get("std", 0.02)))
+        elif state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        else:
+            self._load_safetensors_dir(model_name_or_path)
+        return True, None
+
+    def _load_safetensors_dir(self, path: str) -> None:
+        from safetensors import safe_open
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(
+                f"no *.safetensors under {path!r}: the MI355X plugin loads local HF checkpoints "
+                "(no hub access); use override_mi355x_config['synthetic_weights'] for benchmarks")
+        for f in files:
+            with safe_open(f, "pt") as sf:
+                for name in sf.keys():
+                    t = sf.get_tensor(name)
+                    if t.dim() in (1, 2):
+                        self.model.load_weight(name, t)
+
+
+def _decoder_geometry(hf) -> dict:
+    """HF config -> mi_model_config geometry fields."""
+    head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+    rp = getattr(hf, "rope_parameters", None) or {}
+    rs = getattr(hf, "rope_scaling", None) or rp
+    rope_type = (rs or {}).get("rope_type", (rs or {}).get("type", "default"))
+    if rope_type not in ("default", "llama3", None):
+        raise NotImplementedError(f"rope scaling {rope_type!r} is not supported on MI355X yet")
+    llama3 = rope_type == "llama3"
+    return dict(
+        num_layers=hf.num_hidden_layers, hidden_size=hf.hidden_size, num_heads=hf.num_attention_heads,
+        num_kv_heads=hf.num_key_value_heads, head_dim=int(head_dim), intermediate_size=hf.intermediate_size,
+        vocab_size=hf.vocab_size, rms_norm_eps=float(hf.rms_norm_eps),
+        rope_theta=float(rp.get("rope_theta", getattr(hf, "rope_theta", 10000.0))),
+        rope_type=int(llama3), rope_factor=float(rs["factor"]) if llama3 else 1.0,
+        rope_low_freq_factor=float(rs["low_freq_factor"]) if llama3 else 1.0,
+        rope_high_freq_factor=float(rs["high_freq_factor"]) if llama3 else 4.0,
+        rope_original_max_position=int(rs["original_max_position_embeddings"]) if llama3 else 0,
+        qkv_bias=int(getattr(hf, "model_type", "") == "qwen2" or bool(getattr(hf, "attention_bias", False))),
+        tie_word_embeddings=int(bool(getattr(hf, "tie_word_embeddings", False))))
+
+
+def _get_model_configs(config) -> tuple[str, int, int]:
+    archs = getattr(config, "architectures", [])
+    if not archs:
+        raise ValueError("No architectures specified in the pretrained config.")
+    architecture = archs[0]
+    if architecture in MI355X_MULTI_MODAL_MODELS:
+        config = getattr(config, "text_config", None)
+    num_key_value_heads = getattr(config, "num_key_value_heads", None)
+    head_dim = getattr(config, "head_dim", None)
+    if not head_dim:
+        num_attention_heads = getattr(config, "num_attention_heads", None)
+        hidden_size = getattr(config, "hidden_size", None)
+        if num_attention_heads and hidden_size:
+            head_dim = hidden_size // num_attention_heads
+    if not num_key_value_heads or not head_dim:
+        raise ValueError("Missing required fields in the pretrained config.")
+    return architecture, int(num_key_value_heads), int(head_dim)
+
+
+def _check_architecture(architecture: str) -> None:
+    if architecture not in SUPPORTED_ARCHITECTURES:
+        raise ValueError(f"Model {architecture} is not supported on MI355X for now. "
+                         f"Supported models: {list(SUPPORTED_ARCHITECTURES)}")
+
+
+def get_override_config(additional_config) -> dict | None:
+    for key in OVERRIDE_KEYS:
+        val = (additional_config or {}).get(key)
+        if val is not None:
+            return val
+    return None
+
+
+def get_mi355x_model(model_config, cache_config, parallel_config, scheduler_config, lora_serving_config,
+                     speculative_config=None, additional_config: Any | None = None, **native_kwargs) -> nn.Module:
+    architecture, num_key_value_heads, head_dim = _get_model_configs(model_config.hf_config)
+    if architecture in MI355X_MULTI_MODAL_MODELS:
+        raise NotImplementedError(f"{architecture}: multimodal models are not supported on the MI355X plugin")
+    _check_architecture(architecture)
+    if lora_serving_config:
+        raise NotImplementedError("Multi-lora is not yet supported on the MI355X plugin")
+    if speculative_config is not None:
+        raise NotImplementedError("Speculative decoding is not yet supported on the MI355X plugin")
+
+    model = MI355XCausalLM(model_config.hf_config)
+    default_args = _get_default_mi355x_config(model_config, cache_config, parallel_config, scheduler_config,
+                                              lora_serving_config, speculative_config)
+    override = get_override_config(additional_config)
+    if override is not None:
+        logger.info("override_mi355x_config keys: %s", sorted(override))
+    override = dict(override) if override is not None else None
+    cfg = _get_mi355x_config_after_override(default_args, override)
+    if cfg.get("is_block_kv_layout"):
+        cfg = _handle_pa_num_blocks(cache_config, cfg, override)
+    cfg = _validate_mi355x_config(cache_config, scheduler_config, cfg)
+    if cfg.get("chunked_prefill_config"):
+        raise NotImplementedError("chunked prefill is not implemented on the MI355X plugin")
+
+    model.load_weights(model_name_or_path=model_config.model, architecture=architecture, mi355x_config=cfg,
+                       **native_kwargs)
+    cfg.pop("state_dict", None)
+    model.mi355x_config = MI355XConfig(**{"attn_tkg_nki_kernel_enabled": False,
+                                          "attn_block_tkg_nki_kernel_enabled": False,
+                                          "chunked_prefill_config": None, **cfg})
+    model.architecture = architecture
+    model.num_key_value_heads = num_key_value_heads
+    model.head_dim = head_dim
+    return model.eval()
+
+
+def _get_default_mi355x_config(model_config, cache_config, parallel_config, scheduler_config,
+                               lora_serving_config, speculative_config) -> dict:
+    """Same keys and defaults as the reference's `_get_default_neuron_config`
+    (loader.py:725-793), except `on_device_sampling_config`, which defaults to None here:
+    the CPU-sampling path is the one this backend implements."""
+    if scheduler_config.chunked_prefill_enabled:
+        batch_size = 1
+        max_context_length = scheduler_config.max_num_batched_tokens
+    else:
+        batch_size = scheduler_config.max_num_seqs
+        max_context_length = scheduler_config.max_model_len
+
+    default_num_blocks = ceil(scheduler_config.max_model_len // cache_config.block_size) * scheduler_config.max_num_seqs
+    if cache_config.num_gpu_blocks_override is not None:
+        default_num_blocks = cache_config.num_gpu_blocks_override
+
+    return {
+        "tp_degree": parallel_config.tensor_parallel_size,
+        "ctx_batch_size": 1,
+        "batch_size": batch_size,
+        "max_context_length": max_context_length,
+        "seq_len": scheduler_config.max_model_len,
+        "enable_bucketing": True,
+        "is_continuous_batching": (batch_size > 1),
+        "quantized": False,
+        "torch_dtype": TORCH_DTYPE_TO_MI355X_AMP[model_config.dtype],
+        "padding_side": "right",
+        "on_device_sampling_config": None,
+        "lora_config": lora_serving_config,
+        "pa_num_blocks": default_num_blocks,
+        "pa_block_size": cache_config.block_size,
+        "is_block_kv_layout": (scheduler_config.chunked_prefill_enabled or cache_config.enable_prefix_caching),
+        "is_prefix_caching": cache_config.enable_prefix_caching,
+    }
+
+
+def _handle_pa_num_blocks(cache_config, mi355x_config: dict, override_config: dict | None) -> dict:
+    """Keep vLLM's block count and the pool's in step (reference loader.py:796-831): vLLM saw
+    N + 1 (null block); an explicit pa_num_blocks must equal the user's N and is bumped too."""
+    explicit = bool(override_config) and "pa_num_blocks" in override_config
+    if cache_config.num_gpu_blocks_override is not None:
+        pa_num_blocks = mi355x_config.get("pa_num_blocks")
+        user_blocks = cache_config.num_gpu_blocks_override - 1
+        if explicit:
+            if pa_num_blocks == user_blocks:
+                mi355x_config["pa_num_blocks"] = cache_config.num_gpu_blocks_override
+            else:
+                raise ValueError(
+                    f"pa_num_blocks ({pa_num_blocks}) must match your --num-gpu-blocks-override intent"
+                    f"({user_blocks}) to ensure vLLM and the MI355X KV pool have consistent block counts. ")
+    elif explicit:
+        raise ValueError(
+            f"When setting pa_num_blocks ({mi355x_config.get('pa_num_blocks')}) in override_mi355x_config, "
+            "you must also set --num-gpu-blocks-override to the same value to ensure vLLM and the MI355X KV "
+            "pool have consistent block counts.")
+    return mi355x_config
+
+
+def _validate_mi355x_config(cache_config, scheduler_config, mi355x_config: dict) -> dict:
+    if cache_config.enable_prefix_caching:
+        assert mi355x_config.get("is_prefix_caching", False)
+        assert mi355x_config.get("is_block_kv_layout", False)
+    if scheduler_config.chunked_prefill_enabled:
+        assert mi355x_config.get("chunked_prefill_config")
+        assert mi355x_config.get("is_block_kv_layout", False)
+    if mi355x_config.get("is_block_kv_layout"):
+        min_blocks_required = ceil(scheduler_config.max_model_len / cache_config.block_size) * scheduler_config.max_num_seqs
+        if cache_config.num_gpu_blocks_override is not None:
+            effective_blocks = cache_config.num_gpu_blocks_override - 1
+        else:
+            effective_blocks = mi355x_config.get("pa_num_blocks")
+        assert effective_blocks >= min_blocks_required, (
+            f"At least {min_blocks_required} blocks are required for max_model_len "
+            f"{scheduler_config.max_model_len}, but only {effective_blocks} blocks are available "
+            "(user-intended blocks, excluding the +1 for null block)")
+    assert "text_neuron_config" not in mi355x_config and "vision_neuron_config" not in mi355x_config, (
+        "text/vision sub-configs belong to ImageToText models, which this backend does not implement")
+    return mi355x_config
+
+
+def _get_mi355x_config_after_override(default_config: dict, overridden: dict | None) -> dict:
+    """Shallow merge with the reference's special cases (loader.py:870-900)."""
+    overridden = overridden or {}
+    cfg = overridden.pop("chunked_prefill_config", None)
+    if cfg:
+        overridden["chunked_prefill_config"] = SimpleNamespace(**cfg)
+    default_config.update(overridden)
+    default_config.pop("text_neuron_config", None)
+    default_config.pop("vision_neuron_config", None)
+    if "quantized" in overridden:
+        default_config.update({
+            "quantized": overridden.pop("quantized", False),
+            "quantized_checkpoints_path": overridden.pop("quantized_checkpoints_path", None),
+            "quantization_type": overridden.pop("quantization_type", "per_tensor_symmetric"),
+            "quantization_dtype": overridden.pop("quantization_dtype", "int8"),
+        })
+    return default_config
