@@ -112,6 +112,12 @@ int mi_forward(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_ids,
                const int64_t* full_context_lens, const int64_t* computed_context_lens,
                float* logits_out);
 
+/* Replay the LAST token-generation call `steps` times with its inputs left resident in HBM
+ * (no host round trip in between) and return the elapsed time measured with HIP events on the
+ * context's stream.  For benchmarking the hot path itself: mi_forward adds one small H2D copy
+ * and a [B, V] fp32 D2H copy per step. */
+int mi_replay_decode(mi_ctx* ctx, int32_t steps, float* elapsed_ms);
+
 typedef struct mi_kv_stats_t {
   int64_t kv_bytes, weight_bytes, workspace_bytes, device_free_bytes, device_total_bytes;
   int32_t num_blocks, block_size, num_kv_heads_local, head_dim, num_layers;

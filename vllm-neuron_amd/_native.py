@@ -59,6 +59,7 @@ _SIGS = {
     "mi_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
     "mi_stream": (C.c_void_p, [C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -201,6 +202,13 @@ class NativeModel:
                                   bt.data_ptr(), bt.shape[1], sm.data_ptr(), sm.shape[1],
                                   full.data_ptr(), comp.data_ptr(), out.data_ptr()))
         return out
+
+    def replay_decode(self, steps: int) -> float:
+        """Replay the last token-generation step `steps` times, inputs resident; -> elapsed ms
+        (HIP events on the library's stream)."""
+        ms = C.c_float()
+        check(self.lib.mi_replay_decode(self._ctx, steps, C.byref(ms)))
+        return ms.value
 
     def kv_stats(self) -> dict:
         s = MiKvStats()

@@ -102,6 +102,7 @@ struct mi_ctx {
   int MB_cap = 0;
   size_t weight_bytes = 0, workspace_bytes = 0, kv_bytes = 0;
   std::map<int, hipGraphExec_t> graphs;  // token-generation graph per (B * 65536 + MB)
+  int last_B = 0, last_MB = 0;           // shape of the last token-generation call (mi_replay_decode)
   Prof prof;
   ncclComm_t comm = nullptr;
 };
@@ -754,6 +755,8 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
     MI_HIP(hipMemcpyAsync(c->d_ctx, c->h_ctx, (size_t)B * 4, hipMemcpyHostToDevice, s));
     MI_HIP(hipMemcpyAsync(c->d_bt, c->h_bt, (size_t)B * MB * 4, hipMemcpyHostToDevice, s));
     MI_TRY(capture_or_launch_decode(c, B, MB));
+    c->last_B = B;
+    c->last_MB = MB;
     MI_TRY(fetch_logits(c, B, logits_out));
     return prof_collect(c);
   }
@@ -784,6 +787,24 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
     MI_TRY(run_layers(c, n_new, false, 1, MB, comp, 1, n_new - 1));
     MI_TRY(fetch_logits(c, 1, logits_out + (size_t)b * V));
   }
+  return prof_collect(c);
+}
+
+int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
+  MI_CHECK(c && c->finalized && elapsed_ms, "bad argument");
+  MI_CHECK(c->last_B > 0, "mi_replay_decode needs a preceding token-generation mi_forward");
+  MI_CHECK(steps >= 1, "steps must be >= 1");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  hipEvent_t a, b;
+  MI_HIP(hipEventCreate(&a));
+  MI_HIP(hipEventCreate(&b));
+  MI_HIP(hipEventRecord(a, c->stream));
+  for (int i = 0; i < steps; ++i) MI_TRY(capture_or_launch_decode(c, c->last_B, c->last_MB));
+  MI_HIP(hipEventRecord(b, c->stream));
+  MI_HIP(hipEventSynchronize(b));
+  MI_HIP(hipEventElapsedTime(elapsed_ms, a, b));
+  hipEventDestroy(a);
+  hipEventDestroy(b);
   return prof_collect(c);
 }
 

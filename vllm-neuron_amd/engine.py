@@ -50,7 +50,7 @@ class MI355XEngine:
         MI355XPlatform.check_and_update_config(cfg)
         self.vllm_config = cfg
         self.worker = MI355XWorker(cfg, local_rank=local_rank, rank=rank, distributed_init_method="",
-                                   is_driver_worker=(rank == 0))
+                                   is_driver_worker=True)  # every TP rank holds the full logits (all-gather) and samples identically
         self.worker.init_device()
         self.worker.load_model()
         spec = self.worker.get_kv_cache_spec()["layer"]

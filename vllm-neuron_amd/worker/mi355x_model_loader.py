@@ -183,7 +183,9 @@ class MI355XCausalLM(MI355XModelBase):
             quant_type=_QUANT_TYPES[qtype] if quantized else 0,
             quantize_lm_head=int(quantized and not any("lm_head" in m for m in not_converted)),
             tp_degree=int(cfg["tp_degree"]), tp_rank=tp_rank,
-            device_id=int(kwargs.get("device_id", 0)), use_graphs=int(cfg.get("use_graphs", True)),
+            device_id=int(kwargs.get("device_id", 0)),
+            # collectives are launched eagerly for now: graphs only when a single GPU runs the step
+            use_graphs=int(cfg.get("use_graphs", int(cfg["tp_degree"]) == 1)),
             **geo)
         if cfg["tp_degree"] > 1:
             uid = kwargs.get("tp_unique_id")
