@@ -152,3 +152,41 @@ def test_forward_rejects_bad_inputs():
     with pytest.raises(ValueError, match="nothing to compute"):
         model.forward(**bad)
     model.close()
+
+
+def test_collective_path_single_rank_equals_fused_path():
+    """The tensor-parallel code path (fp32 partial -> RCCL all-reduce -> partial folded in by the
+    next norm prologue, vocab all-gather) with a ONE-rank communicator must give bit-identical
+    logits to the single-GPU path (projection written straight into the residual stream):
+    same fp32 additions in the same order.  Exercises the RCCL linkage on a 1-GPU box."""
+    name = "llama31_like"
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=1)
+    gen, _, _ = load_golden(name)
+    prompts = make_prompts(cfg.vocab_size, 0)
+    outs = []
+    for with_comm in (False, True):
+        from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+        rs = cfg.rope_scaling or {}
+        m = NativeModel(
+            num_layers=cfg.num_layers, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads,
+            num_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+            vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+            rope_type=1, rope_factor=rs["factor"], rope_low_freq_factor=rs["low_freq_factor"],
+            rope_high_freq_factor=rs["high_freq_factor"],
+            rope_original_max_position=rs["original_max_position_embeddings"], qkv_bias=0, tie_word_embeddings=0,
+            num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN, weight_dtype=MI_W["f8e4m3"],
+            quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1, tp_degree=1, tp_rank=0, device_id=0,
+            use_graphs=0)
+        if with_comm:
+            m.tp_init(m.tp_unique_id())
+        m.load_state_dict(w)
+        m.finalize()
+        outs.append([m.forward(**inp) for _, inp, _ in scenario(prompts, gen)])
+        if with_comm:
+            m.profile_enable(True)
+            m.forward(**list(scenario(prompts, gen))[-1][1])
+            assert m.profile_read()["launches"]["comm"] == 2 * cfg.num_layers + 1
+        m.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -192,7 +192,7 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
 }
 
 int all_reduce_partial(mi_ctx* c, int rows) {
-  if (c->cfg.tp_degree <= 1) return MI_OK;
+  if (!c->comm) return MI_OK;
   Scope sc(c, MI_K_COMM);
   ncclResult_t r = ncclAllReduce(c->partial, c->partial, (size_t)rows * c->H, ncclFloat, ncclSum, c->comm, c->stream);
   if (r != ncclSuccess) {
@@ -242,7 +242,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
                                  c->nkv_l, c->hd, c->attn_out, s));
     }
-    const bool tp = k.tp_degree > 1;
+    const bool tp = c->comm != nullptr;  // a communicator (even of one rank) selects the collective path
     {  // O projection.  TP = 1: straight into the residual stream (resid' = resid + y);
        // TP > 1: fp32 partial -> RCCL all-reduce -> folded in by the next norm prologue.
       ProArgs p{};
@@ -297,7 +297,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     e.out_f32 = c->logits; e.ld_out = c->V_l;
     MI_TRY(run_linear(c, c->lm_head, logits_rows, PRO_NORM, p, EPI_F32, e));
   }
-  if (k.tp_degree > 1) {
+  if (c->comm) {
     Scope sc(c, MI_K_COMM);
     ncclResult_t r = ncclAllGather(c->logits, c->logits_all, (size_t)k.max_num_seqs * c->V_l, ncclFloat, c->comm, s);
     if (r != ncclSuccess) {
@@ -311,7 +311,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
 int fetch_logits(mi_ctx* c, int nrows, float* out) {
   const mi_model_config& k = c->cfg;
   const int V = k.vocab_size;
-  if (k.tp_degree <= 1) {
+  if (!c->comm) {
     MI_HIP(hipMemcpyAsync(c->h_logits, c->logits, (size_t)nrows * V * 4, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_logits, (size_t)nrows * V * 4);
@@ -688,7 +688,7 @@ int mi_finalize(mi_ctx* c) {
   MI_TRY(dmalloc(&c->attn_out, R * c->q_dim, ws));
   MI_TRY(dmalloc(&c->act, R * c->I_l, ws));
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
-  if (k.tp_degree > 1) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
+  if (c->comm) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
   MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
   *ws += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
   c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
