@@ -1,7 +1,8 @@
 """Summarise a rocprofv3 kernel trace CSV: per kernel name x grid, count / median / min us."""
 import collections, csv, glob, sys
 d = sys.argv[1]
-f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]

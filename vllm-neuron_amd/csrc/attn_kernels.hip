@@ -240,131 +240,245 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
 // =====================================================================================
 // context encoding
 // =====================================================================================
-// Work-group = 4 waves = 64 queries of one head; wave w owns queries 16w..16w+15.
-// Per 32-key tile:  S^T_u[key][q] = K_u . Q^T   (u = 0,1: two 16-key MFMA tiles)
-//                   O^T[d][q]    += V^T[d][key] . P^T[key][q]
-// The MFMA k-slot (g, j) of the P.V product is bound to key (j < 4 ? 4g + j : 16 + 4g + j - 4),
-// which is where S^T_0 / S^T_1 already hold that key's score for lane (g, q) — so the
-// exponentiated accumulators are the B operand as they stand, and V^T is staged with its
-// keys in that order (perm below).
-template <int HD>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(
-    const uint16_t* __restrict__ q, int T, int q_pos0, const uint16_t* __restrict__ kpool,
-    const uint16_t* __restrict__ vpool, int bs, const int32_t* __restrict__ block_table, int nh, int nkv,
-    uint16_t* __restrict__ out, float scale_log2e) {
-  constexpr int KP = HD + 8;   // K row pitch (elements): +16 B
-  constexpr int VP = 32 + 8;   // V^T row pitch
-  constexpr int CPR = HD / 8;  // 16-byte chunks per row
-  constexpr int DN = HD / 16;
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[32 * KP];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[HD * VP];
+// One work-group per (32*QB queries, kv head): wave w owns q head (w % Gp) of the kv group and
+// query block (w / Gp), i.e. 32 queries = two 16-query MFMA tiles that share every K / V
+// fragment; the G heads of the group share the K/V tiles staged in LDS (one HBM read per group).
+// Per 64-key tile:  S^T_u[key][q] = K_u . Q^T        (u = 0..3: four 16-key MFMA tiles)
+//                   O^T[d][q]    += V^T[d][key] . P^T[key][q]   (two k-steps of 32 keys)
+// The MFMA k-slot (g, j) of P.V k-step kk is bound to key 32 kk + (j < 4 ? 4g + j : 16 + 4g + j - 4),
+// which is where S^T_{2kk} / S^T_{2kk+1} already hold that key's score for lane (g, q): the
+// exponentiated accumulators are the B operand as they stand (no LDS round trip for P).  V stays
+// row-major in LDS; its transposed A fragments come from ds_read_b64_tr_b16 (4 keys x 16 dims
+// per 16-lane group).  Next tile's K/V are prefetched into registers under the MFMAs.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+constexpr int kPrefillMaxBlocks = 2048;
 
-  const int head = blockIdx.y, kvh = head / (nh / nkv);
-  const int q0 = blockIdx.x * 64;
+template <int HD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
+    const uint16_t* __restrict__ q, int T, int q_pos0, const uint16_t* __restrict__ kpool,
+    const uint16_t* __restrict__ vpool, int bs, const int32_t* __restrict__ block_table, int nh, int nkv, int G,
+    int Gp, uint16_t* __restrict__ out, float scale_log2e) {
+  constexpr int KP = HD + 8;    // row pitch (elements): +16 B keeps ds_read_b128 / tr reads off one bank window
+  constexpr int CPR = HD / 8;   // 16-byte chunks per row
+  constexpr int DN = HD / 16, KS = HD / 32;
+  constexpr int TK = 64;        // keys per tile
+  constexpr int LD = (TK * CPR) / (WAVES * 64);  // 16-byte loads per thread per K (or V) tile
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[TK * KP];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[TK * KP];
+  __shared__ int32_t bt_lds[kPrefillMaxBlocks];   // this sequence's block table: one L2 trip, not one per tile
+
+  constexpr int nthr = WAVES * 64, waves = WAVES;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int qi = q0 + wave * 16 + c;            // this lane's query (column of S^T / O^T)
-  const bool qvalid = qi < T;
-  const int qpos = q_pos0 + (qvalid ? qi : 0);
-
-  // Q^T fragments: lane (g, c) holds Q[q = c][32 ks + 8 g .. +8]
-  uint4 qf[HD / 32];
-#pragma unroll
-  for (int ks = 0; ks < HD / 32; ++ks)
-    qf[ks] = qvalid ? *reinterpret_cast<const uint4*>(q + ((size_t)qi * nh + head) * HD + ks * 32 + g * 8)
-                    : make_uint4(0, 0, 0, 0);
-
-  f32x4_t acc[DN];
-#pragma unroll
-  for (int dn = 0; dn < DN; ++dn) acc[dn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float mrow = -INFINITY, lrow = 0.f;
-
-  const int last_q = min(q0 + 63, T - 1);
-  const int ntiles = (q_pos0 + last_q) / 32 + 1;
+  const int kvh = blockIdx.y, QB = waves / Gp;
+  const int hl = wave % Gp, qb = wave / Gp;
+  const bool head_ok = hl < G;
+  const int head = kvh * G + min(hl, G - 1);
   const int kv_len = q_pos0 + T;
+  for (int i = threadIdx.x; i < ceil_div(kv_len, bs); i += nthr) bt_lds[i] = block_table[i];
 
-  for (int tile = 0; tile < ntiles; ++tile) {
-    __syncthreads();  // previous tile's LDS reads are done
-    for (int idx = tid; idx < 32 * CPR; idx += 256) {
-      const int tok = idx / CPR, ch = idx % CPR;
-      const int ta = tile * 32 + tok;
-      uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = kv4;
-      if (ta < kv_len) {
-        const int blk = block_table[ta / bs];
-        const size_t src = (((size_t)blk * nkv + kvh) * bs + (ta % bs)) * HD + ch * 8;
-        kv4 = *reinterpret_cast<const uint4*>(kpool + src);
-        vv4 = *reinterpret_cast<const uint4*>(vpool + src);
-      }
-      *reinterpret_cast<uint4*>(&Ks[tok * KP + ch * 8]) = kv4;
-      const int r = tok & 15;
-      const int pcol = 8 * (r >> 2) + 4 * (tok >> 4) + (r & 3);  // key -> P.V k-slot
-      const uint32_t vw[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+  // Causal work grows linearly with the query block index, so a work-group takes block x and
+  // then its complement (nblk - 1 - x): every work-group does the same number of key tiles.
+  const int nblk = ceil_div(T, 32 * QB);
+  for (int pass = 0; pass < 2; ++pass) {
+  const int xb = pass == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+  if (pass == 1 && xb <= (int)blockIdx.x) break;   // odd count: the middle block is done once
+  const int wg_q0 = xb * 32 * QB;
+  const int q0 = wg_q0 + 32 * qb;            // this wave's 32 queries
+
+  u32x4_t qf[2][KS];
+  int qpos[2];
+  bool qok[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        Vt[(ch * 8 + e) * VP + pcol] = (uint16_t)(vw[e >> 1] >> (16 * (e & 1)));
+  for (int t = 0; t < 2; ++t) {
+    const int qi = q0 + 16 * t + c;
+    qok[t] = head_ok && qi < T;
+    qpos[t] = q_pos0 + min(qi, T - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[t][ks] = qok[t] ? *reinterpret_cast<const u32x4_t*>(q + ((size_t)qi * nh + head) * HD + ks * 32 + g * 8)
+                         : u32x4_t{0, 0, 0, 0};
+  }
+  f32x4_t acc[2][DN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dn = 0; dn < DN; ++dn) acc[t][dn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+
+  const int wg_last_pos = q_pos0 + min(wg_q0 + 32 * QB - 1, T - 1);
+  const int ntiles = wg_last_pos / TK + 1;
+  const int w_first_pos = q_pos0 + min(q0, T - 1), w_last_pos = q_pos0 + min(q0 + 31, T - 1);
+
+  __syncthreads();   // block table staged (pass 0) / previous pass done with the K/V tiles
+  // register prefetch of one K/V tile (each thread: LD chunks of K and of V)
+  // Two register sets, two tiles ahead: with one wave per SIMD a tile's arithmetic (~1 us) is
+  // shorter than an HBM round trip, so the tile after next is requested before this one is used.
+  // (ext vectors: hipcc keeps arrays of them in VGPRs; HIP's uint4 struct goes to scratch)
+  u32x4_t kregA[LD], vregA[LD], kregB[LD], vregB[LD];
+  auto prefetch = [&](u32x4_t (&kreg)[LD], u32x4_t (&vreg)[LD], int tile) {
+    tile = min(tile, ntiles - 1);
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + i * nthr;
+      const int key = idx / CPR, ch = idx % CPR;
+      const int ta = min(tile * TK + key, kv_len - 1);   // clamp: rows past the context are masked anyway
+      const int blk = bt_lds[ta / bs];
+      const size_t src = (((size_t)blk * nkv + kvh) * bs + (ta % bs)) * HD + ch * 8;
+      kreg[i] = *reinterpret_cast<const u32x4_t*>(kpool + src);
+      vreg[i] = *reinterpret_cast<const u32x4_t*>(vpool + src);
+    }
+  };
+  prefetch(kregA, vregA, 0);
+  prefetch(kregB, vregB, 1);
+
+  auto do_tile = [&](u32x4_t (&kreg)[LD], u32x4_t (&vreg)[LD], int tile) {
+    __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + i * nthr;
+      const int key = idx / CPR, ch = idx % CPR;
+      *reinterpret_cast<u32x4_t*>(&Ks[key * KP + ch * 8]) = kreg[i];
+      *reinterpret_cast<u32x4_t*>(&Vs[key * KP + ch * 8]) = vreg[i];
     }
     __syncthreads();
+    prefetch(kreg, vreg, tile + 2);
+    if (tile * TK > w_last_pos) return;   // wave-uniform: every key of this tile is in this wave's future
 
-    // S^T_u = K_u . Q^T
-    f32x4_t st[2];
+    // ---- S^T = K . Q^T ------------------------------------------------------------------
+    // One wave per SIMD: latency is hidden by issue order, not by other waves.  All 16 K
+    // fragments are requested first, then the 32 MFMAs run back to back.
+    bf16x8_t kf[4][KS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      st[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int ks = 0; ks < HD / 32; ++ks) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&Ks[(16 * u + c) * KP + ks * 32 + g * 8]);
-        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, qf[ks]), st[u], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks)
+        kf[u][ks] = *reinterpret_cast<const bf16x8_t*>(&Ks[(16 * u + c) * KP + ks * 32 + g * 8]);
+    f32x4_t st[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      st[u][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st[u][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        st[u][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][ks], __builtin_bit_cast(bf16x8_t, qf[0][ks]), st[u][0], 0, 0, 0);
+        st[u][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][ks], __builtin_bit_cast(bf16x8_t, qf[1][ks]), st[u][1], 0, 0, 0);
       }
     }
-    // causal mask + online softmax for query c (its keys are spread over the 4 lanes g)
-    float mx = -INFINITY;
+    // V^T fragments for the P.V product: requested now, so their LDS latency runs under the
+    // softmax arithmetic.  tr read: lane 4q' + p of a 16-lane group addresses row q' (a key),
+    // columns 4p..4p+3 (dims); lane i receives column i (dim 16 dn + i) of the 4 rows = 4
+    // consecutive k-slots of the A fragment.
+    const int tr_row = (lane & 15) >> 2, tr_col = (lane & 3) * 4;
+    s16x4_t vlo[2][DN], vhi[2][DN];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int key = tile * 32 + 16 * u + 4 * g + i;
-        const float sv = (key <= qpos) ? st[u][i] * scale_log2e : -INFINITY;
-        st[u][i] = sv;
-        mx = fmaxf(mx, sv);
+      for (int dn = 0; dn < DN; ++dn) {
+        const uint16_t* r0 = &Vs[(32 * kk + 4 * g + tr_row) * KP + 16 * dn + tr_col];
+        vlo[kk][dn] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)r0);
+        vhi[kk][dn] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(r0 + 16 * KP));
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mn = fmaxf(mrow, mx);
-    const float alpha = sexp2(mrow, mn);
-    mrow = mn;
-    float ps = 0.f;
-    float pv[8];
+    // ---- causal mask + online softmax (query c of q-tile t; its keys sit on the 4 lanes g) --
+    // Only the tiles that straddle the diagonal need the mask; every other tile takes the lean
+    // path: max on the raw scores, then one fma + one exp2 per score.  The O^T rescale is skipped
+    // (exactly: alpha == 1) when no lane's running maximum moved.
+    const bool need_mask = tile * TK + TK - 1 > w_first_pos;
+    bf16x8_t pb[2][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int t = 0; t < 2; ++t) {
+      float pv[16];
+      float mn, alpha, ps = 0.f;
+      if (need_mask) {
+        float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float pe = sexp2(st[u][i], mn);
-        pv[4 * u + i] = pe;
-        ps += pe;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float sv = st[u][t][i] * scale_log2e;
+            if (tile * TK + 16 * u + 4 * g + i > qpos[t]) sv = -INFINITY;
+            st[u][t][i] = sv;
+            mx = fmaxf(mx, sv);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mn = fmaxf(mrow[t], mx);
+        alpha = sexp2(mrow[t], mn);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pv[4 * u + i] = sexp2(st[u][t][i], mn);
+            ps += pv[4 * u + i];
+          }
+      } else {
+        float mx = st[0][t][0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mx = fmaxf(mx, st[u][t][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mn = fmaxf(mrow[t], mx * scale_log2e);      // finite: every key of the tile is visible
+        alpha = fexp2(mrow[t] - mn);                // exp2(-inf) = 0 on the first tile
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pv[4 * u + i] = fexp2(fmaf(st[u][t][i], scale_log2e, -mn));
+            ps += pv[4 * u + i];
+          }
       }
-    lrow = lrow * alpha + ps;
-    union { uint32_t w[4]; bf16x8_t v; } pb;
+      const bool moved = mn != mrow[t];
+      mrow[t] = mn;
+      lrow[t] = lrow[t] * alpha + ps;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pb.w[k] = pack_bf16x2(pv[2 * k], pv[2 * k + 1]);
+      for (int kk = 0; kk < 2; ++kk) {
+        union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-    for (int dn = 0; dn < DN; ++dn) {
-      acc[dn][0] *= alpha; acc[dn][1] *= alpha; acc[dn][2] *= alpha; acc[dn][3] *= alpha;
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&Vt[(16 * dn + c) * VP + 8 * g]);
-      acc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb.v, acc[dn], 0, 0, 0);
+        for (int k = 0; k < 4; ++k) pk.w[k] = pack_bf16x2(pv[8 * kk + 2 * k], pv[8 * kk + 2 * k + 1]);
+        pb[t][kk] = pk.v;
+      }
+      if (__any(moved)) {
+#pragma unroll
+        for (int dn = 0; dn < DN; ++dn) {
+          acc[t][dn][0] *= alpha; acc[t][dn][1] *= alpha; acc[t][dn][2] *= alpha; acc[t][dn][3] *= alpha;
+        }
+      }
+    }
+    // ---- O^T += V^T . P^T ----------------------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int dn = 0; dn < DN; ++dn) {
+        const s16x4_t lo = vlo[kk][dn], hi = vhi[kk][dn];
+        const bf16x8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        acc[0][dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[0][kk], acc[0][dn], 0, 0, 0);
+        acc[1][dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[1][kk], acc[1][dn], 0, 0, 0);
+      }
+    }
+  };
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    do_tile(kregA, vregA, tile);
+    if (tile + 1 < ntiles) do_tile(kregB, vregB, tile + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float lsum = lrow[t];
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    if (qok[t]) {
+      const float inv = 1.f / lsum;
+      uint16_t* orow = out + ((size_t)(q0 + 16 * t + c) * nh + head) * HD;
+#pragma unroll
+      for (int dn = 0; dn < DN; ++dn) {
+        const uint2 pk = make_uint2(pack_bf16x2(acc[t][dn][0] * inv, acc[t][dn][1] * inv),
+                                    pack_bf16x2(acc[t][dn][2] * inv, acc[t][dn][3] * inv));
+        *reinterpret_cast<uint2*>(orow + 16 * dn + 4 * g) = pk;
+      }
     }
   }
-  lrow += __shfl_xor(lrow, 16);
-  lrow += __shfl_xor(lrow, 32);
-  if (qvalid) {
-    const float inv = 1.f / lrow;
-    uint16_t* orow = out + ((size_t)qi * nh + head) * HD;
-#pragma unroll
-    for (int dn = 0; dn < DN; ++dn) {
-      const uint2 pk = make_uint2(pack_bf16x2(acc[dn][0] * inv, acc[dn][1] * inv),
-                                  pack_bf16x2(acc[dn][2] * inv, acc[dn][3] * inv));
-      *reinterpret_cast<uint2*>(orow + 16 * dn + 4 * g) = pk;
-    }
-  }
+  }  // pass
 }
 
 int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kpool, const uint16_t* vpool,
@@ -372,12 +486,17 @@ int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kp
                         hipStream_t s) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
   MI_CHECK(T >= 1 && q_pos0 >= 0, "attention: bad T / q_pos0");
+  MI_CHECK(nh % nkv == 0 && nh / nkv <= 8, "attention: q heads per kv head must be 1..8");
+  MI_CHECK(ceil_div(q_pos0 + T, block_size) <= kPrefillMaxBlocks, "attention: context spans too many blocks");
+  const int G = nh / nkv;
+  const int Gp = G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8));
+  const int waves = Gp < 4 ? 4 : Gp, QB = waves / Gp;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-  const dim3 grid(ceil_div(T, 64), nh);
-  if (hd == 128)
-    hipLaunchKernelGGL((attn_prefill_kernel<128>), grid, dim3(256), 0, s, q, T, q_pos0, kpool, vpool, block_size, block_table, nh, nkv, out, scale_log2e);
-  else
-    hipLaunchKernelGGL((attn_prefill_kernel<64>), grid, dim3(256), 0, s, q, T, q_pos0, kpool, vpool, block_size, block_table, nh, nkv, out, scale_log2e);
+  const dim3 grid(ceil_div(ceil_div(T, 32 * QB), 2), nkv);   // complementary query blocks are paired
+#define MI_PF(HD_, W_) hipLaunchKernelGGL((attn_prefill_kernel<HD_, W_>), grid, dim3(W_ * 64), 0, s, q, T, q_pos0, kpool, vpool, block_size, block_table, nh, nkv, G, Gp, out, scale_log2e)
+  if (hd == 128) { if (waves == 4) MI_PF(128, 4); else MI_PF(128, 8); }
+  else { if (waves == 4) MI_PF(64, 4); else MI_PF(64, 8); }
+#undef MI_PF
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -132,137 +132,167 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-// Stage the activations into LDS in MFMA-fragment order.
-//
-// Rows go 4 at a time with CLAMPED indices (no predication), so all global loads of a group
-// are in flight together: one L2 round trip per group when K <= 8 * threads.
-// (A wave's loads retire in order, so these operands arrive behind the weight batch that was
-// requested just before; moving them in front of it is the next step for the short kernels.)
-template <int WD, int PRO>
-__device__ __forceinline__ void gemv_stage_x(const ProArgs& p, int M, int K, uint4* xf, float* red_f) {
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int nchunk = K >> 3;
+// ---- staging of the activations into LDS (MFMA-fragment order) ----------------------------
+// A wave's vector loads retire IN ORDER.  Operands requested after the first weight batch only
+// arrive once those weights have crossed the chip (microseconds when every CU asks at once), so
+// the kernel requests its own L2-resident operands FIRST (gemv_pro_load), then the first weight
+// batch, and only then consumes the operands (gemv_pro_finish): the prologue arithmetic runs
+// under the weight fetch.  What does not fit that scheme (K > 8 * threads, M > 4 with a norm
+// prologue, > kXMax chunks per thread) goes through gemv_stage_late after the weights.
+constexpr int kXMax = 16;  // 16-byte activation chunks one thread may hold ahead of the weights
+
+// register-resident prologue operands (plain local arrays: hipcc keeps them in VGPRs)
+template <int PRO> struct ProShape {
+  static constexpr int NX = PRO == PRO_BF16 ? kXMax : 1;       // 16-byte activation chunks
+  static constexpr int NH = PRO == PRO_BF16 ? 1 : 4;           // residual rows
+  static constexpr int NP = PRO == PRO_NORM_PARTIAL ? 4 : 1;   // partial rows
+};
+template <int PRO>
+__device__ __forceinline__ bool gemv_pro_is_early(int M, int K) {
+  if constexpr (PRO == PRO_BF16) return true;                    // (first kXMax chunks per thread)
+  else return (K >> 3) <= (int)blockDim.x && M <= 4;
+}
+
+template <int PRO>
+__device__ __forceinline__ void gemv_pro_load(const ProArgs& p, int M, int K, u32x4_t (&xv)[ProShape<PRO>::NX],
+                                              float (&h)[ProShape<PRO>::NH][8], float (&pv)[ProShape<PRO>::NP][8],
+                                              float (&g)[8]) {
+  const int tid = threadIdx.x, nthr = blockDim.x, nchunk = K >> 3;
   if constexpr (PRO == PRO_BF16) {
     const int total = M * nchunk;
-    bool first = true;
-    for (int i0 = tid; i0 < total || first; i0 += 4 * nthr) {
-      uint4 v0, v1, v2, v3;
-      int s0, s1, s2, s3;
-      auto ld = [&](int i, uint4& v, int& slot) {
-        const int ic = min(i, total - 1);   // clamp instead of branching: 4 loads in flight
-        const int m = ic / nchunk, c8 = ic - m * nchunk;
-        v = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
-        slot = xfrag_slot<WD>(c8, m, M);
-      };
-      ld(i0, v0, s0);
-      ld(i0 + nthr, v1, s1);
-      ld(i0 + 2 * nthr, v2, s2);
-      ld(i0 + 3 * nthr, v3, s3);
-      first = false;
-      if (i0 < total) xf[s0] = v0;
-      if (i0 + nthr < total) xf[s1] = v1;
-      if (i0 + 2 * nthr < total) xf[s2] = v2;
-      if (i0 + 3 * nthr < total) xf[s3] = v3;
+#pragma unroll
+    for (int q = 0; q < kXMax; ++q) {
+      const int ic = min(tid + q * nthr, total - 1);   // clamped, never predicated
+      const int m = ic / nchunk, c8 = ic - m * nchunk;
+      xv[q] = *reinterpret_cast<const u32x4_t*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
     }
   } else {
-    // h = resid_in (+ partial); rmsnorm in fp32; x = bf16(h * rsqrt(mean h^2 + eps) * gain)
+    const int c0 = min(tid, nchunk - 1);
+    load8(p.gain + c0 * 8, g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)min(r, M - 1) * K + c0 * 8, h[r]);
+    if constexpr (PRO == PRO_NORM_PARTIAL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)min(r, M - 1) * K + c0 * 8, pv[r]);
+    }
+  }
+}
+
+// bf16(h * rinv * g) -> fragment slot; optionally h -> resid_out (block 0 only)
+template <int WD>
+__device__ __forceinline__ void gemv_emit_row(const ProArgs& p, int M, int K, int m, int c8, const float (&h)[8],
+                                              const float (&g)[8], float rinv, uint4* xf) {
+  if (p.resid_out && blockIdx.x == 0) {
+    float* o = p.resid_out + (size_t)m * K + c8 * 8;
+    *reinterpret_cast<float4*>(o) = make_float4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(h[4], h[5], h[6], h[7]);
+  }
+  uint4 o4;
+  o4.x = pack_bf16x2(h[0] * rinv * g[0], h[1] * rinv * g[1]);
+  o4.y = pack_bf16x2(h[2] * rinv * g[2], h[3] * rinv * g[3]);
+  o4.z = pack_bf16x2(h[4] * rinv * g[4], h[5] * rinv * g[5]);
+  o4.w = pack_bf16x2(h[6] * rinv * g[6], h[7] * rinv * g[7]);
+  xf[xfrag_slot<WD>(c8, m, M)] = o4;
+}
+
+template <int WD, int PRO>
+__device__ __forceinline__ void gemv_pro_finish(const ProArgs& p, int M, int K, u32x4_t (&xv)[ProShape<PRO>::NX],
+                                                float (&h)[ProShape<PRO>::NH][8], float (&pv)[ProShape<PRO>::NP][8],
+                                                float (&g)[8], uint4* xf, float* red_f) {
+  const int tid = threadIdx.x, nthr = blockDim.x, nchunk = K >> 3;
+  if constexpr (PRO == PRO_BF16) {
+    const int total = M * nchunk;
+#pragma unroll
+    for (int q = 0; q < kXMax; ++q) {
+      const int i = tid + q * nthr;
+      if (i < total) {
+        const int m = i / nchunk, c8 = i - m * nchunk;
+        reinterpret_cast<u32x4_t*>(xf)[xfrag_slot<WD>(c8, m, M)] = xv[q];
+      }
+    }
+    for (int i = tid + kXMax * nthr; i < total; i += nthr) {   // rare: more than kXMax chunks per thread
+      const int m = i / nchunk, c8 = i - m * nchunk;
+      xf[xfrag_slot<WD>(c8, m, M)] = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+    }
+  } else {
     const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
-    const bool fast = nchunk <= nthr;   // one 8-element chunk per thread and row: h stays in registers
-    for (int m0 = 0; m0 < M; m0 += 4) {
-      int row[4];
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) row[r] = min(m0 + r, M - 1);
-      float ss[4] = {0.f, 0.f, 0.f, 0.f};
-      float h[4][8], g[8];
-      const int c0 = min(tid, nchunk - 1);
-      if (fast) {
-        load8(p.gain + c0 * 8, g);
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c0 * 8, h[r]);
-        if constexpr (PRO == PRO_NORM_PARTIAL) {
-          float pv[4][8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c0 * 8, pv[r]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
-        }
-        if (tid < nchunk) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
-        }
-      } else {
-        for (int c8 = tid; c8 < nchunk; c8 += nthr) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
-          if constexpr (PRO == PRO_NORM_PARTIAL) {
-            float pv[4][8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c8 * 8, pv[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
-        }
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (PRO == PRO_NORM_PARTIAL) h[r][e] += pv[r][e];
+        ss[r] += h[r][e] * h[r][e];
       }
+      if (tid >= nchunk) ss[r] = 0.f;
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t = wave_sum(ss[r]);
-        if (lane == 0) red_f[(m0 + r) * 16 + wave] = t;
-      }
-      __syncthreads();
-      float rinv[4];
+    for (int r = 0; r < 4; ++r) {
+      const float t = wave_sum(ss[r]);
+      if (lane == 0) red_f[r * 16 + wave] = t;
+    }
+    __syncthreads();
+    if (tid < nchunk) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float tot = 0.f;
-        for (int w = 0; w < nw; ++w) tot += red_f[(m0 + r) * 16 + w];
-        rinv[r] = rsqrtf(tot / (float)K + p.eps);
+        for (int w = 0; w < nw; ++w) tot += red_f[r * 16 + w];
+        if (r < M) gemv_emit_row<WD>(p, M, K, r, tid, h[r], g, rsqrtf(tot / (float)K + p.eps), xf);
       }
-      auto emit = [&](int c8) {
+    }
+  }
+}
+
+// General norm prologue (any M <= 16, any K), requested after the first weight batch.
+template <int WD, int PRO>
+__device__ __forceinline__ void gemv_stage_late(const ProArgs& p, int M, int K, uint4* xf, float* red_f) {
+  const int tid = threadIdx.x, nthr = blockDim.x, nchunk = K >> 3;
+  const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+  for (int m0 = 0; m0 < M; m0 += 4) {
+    int row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) row[r] = min(m0 + r, M - 1);
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    float h[4][8], g[8];
+    auto load_rows = [&](int c8) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
+      if constexpr (PRO == PRO_NORM_PARTIAL) {
+        float pv[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c8 * 8, pv[r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (m0 + r < M) {
-            const size_t o = (size_t)(m0 + r) * K + c8 * 8;
-            if (p.resid_out && blockIdx.x == 0) {
-              *reinterpret_cast<float4*>(p.resid_out + o) = make_float4(h[r][0], h[r][1], h[r][2], h[r][3]);
-              *reinterpret_cast<float4*>(p.resid_out + o + 4) = make_float4(h[r][4], h[r][5], h[r][6], h[r][7]);
-            }
-            uint4 o4;
-            o4.x = pack_bf16x2(h[r][0] * rinv[r] * g[0], h[r][1] * rinv[r] * g[1]);
-            o4.y = pack_bf16x2(h[r][2] * rinv[r] * g[2], h[r][3] * rinv[r] * g[3]);
-            o4.z = pack_bf16x2(h[r][4] * rinv[r] * g[4], h[r][5] * rinv[r] * g[5]);
-            o4.w = pack_bf16x2(h[r][6] * rinv[r] * g[6], h[r][7] * rinv[r] * g[7]);
-            xf[xfrag_slot<WD>(c8, m0 + r, M)] = o4;
-          }
-      };
-      if (fast) {
-        if (tid < nchunk) emit(tid);
-      } else {
-        // second pass re-reads h (L2-hot; again all rows of the group in one round trip)
-        for (int c8 = tid; c8 < nchunk; c8 += nthr) {
-          load8(p.gain + c8 * 8, g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
-          if constexpr (PRO == PRO_NORM_PARTIAL) {
-            float pv[4][8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) load8(p.partial + (size_t)row[r] * K + c8 * 8, pv[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
-          }
-          emit(c8);
-        }
+          for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
       }
+    };
+    for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+      load_rows(c8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = wave_sum(ss[r]);
+      if (lane == 0) red_f[(m0 + r) * 16 + wave] = t;
+    }
+    __syncthreads();
+    float rinv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float tot = 0.f;
+      for (int w = 0; w < nw; ++w) tot += red_f[(m0 + r) * 16 + w];
+      rinv[r] = rsqrtf(tot / (float)K + p.eps);
+    }
+    for (int c8 = tid; c8 < nchunk; c8 += nthr) {   // second pass re-reads h (L2-hot)
+      load8(p.gain + c8 * 8, g);
+      load_rows(c8);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (m0 + r < M) gemv_emit_row<WD>(p, M, K, m0 + r, c8, h[r], g, rinv[r], xf);
     }
   }
 }
@@ -310,9 +340,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
     for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * 64);
   };
 
-  // scale / bias of local tile slot j = (pass * TPW + sub-tile), 16 floats each: requested
-  // before the weights (see gemv_stage_x), parked in LDS afterwards
-  const int nsc = my_units * TPW * 16;
+  // ---- prologue: own operands first, then the first weight batch, then consume (see above) ---
+  const int nsc = my_units * TPW * 16;   // scale / bias of local tile slot j = pass * TPW + sub-tile
   float scv[2], biv[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -322,9 +351,14 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
     scv[q] = e.scale[tile * 16 + r];
     biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
   }
-  if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
+  u32x4_t pro_x[ProShape<PRO>::NX];
+  float pro_h[ProShape<PRO>::NH][8], pro_p[ProShape<PRO>::NP][8], pro_g[8];
+  const bool early = gemv_pro_is_early<PRO>(M, K);
+  gemv_pro_load<PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g);   // unconditional (clamped); ignored on the late path
+  __builtin_amdgcn_sched_barrier(0);
   issue(bufA, 0);
-  gemv_stage_x<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int j = tid + q * (int)blockDim.x;
@@ -333,6 +367,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
       bi_lds[j] = biv[q];
     }
   }
+  if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, reinterpret_cast<float*>(red));
+  else gemv_stage_late<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
   __syncthreads();
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
