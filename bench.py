@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--ttft-prompts", type=int, default=8, help="prompts per context-encoding bucket")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weight-dtype", default="f8e4m3", choices=["f8e4m3", "int8", "bf16"])
+    ap.add_argument("--bf16-prefill-activations", action="store_true",
+                    help="weight-only quantization in the context-encoding GEMMs too (default: FP8 x FP8)")
     args = ap.parse_args()
 
     import torch
@@ -154,6 +156,9 @@ def main():
     if args.weight_dtype != "bf16":
         override.update(quantized=True, quantization_dtype=args.weight_dtype,
                         quantization_type="per_channel_symmetric")
+    if args.weight_dtype == "f8e4m3" and not args.bf16_prefill_activations:
+        # context-encoding GEMMs: per-token FP8 activations on the MX-scaled MFMA (FP8 x FP8)
+        override["prefill_fp8_activations"] = True
     t0 = time.perf_counter()
     eng = MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
                        num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True,
@@ -229,7 +234,9 @@ def main():
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": {"f8e4m3": "fp8_e4m3 weights x bf16 activations, f32 accumulate",
+            "dtype": {"f8e4m3": ("fp8_e4m3 weights; token generation x bf16 activations, context encoding x "
+                                 + ("bf16" if args.bf16_prefill_activations else "per-token fp8_e4m3")
+                                 + " activations; f32 accumulate"),
                       "int8": "int8 weights x bf16 activations, f32 accumulate",
                       "bf16": "bf16, f32 accumulate"}[args.weight_dtype],
             "data": "synthetic (seeded N(0,0.02) weights at real shapes; random token ids)",

@@ -77,6 +77,10 @@ typedef struct mi_model_config {
   int32_t tp_degree, tp_rank;
   int32_t device_id;
   int32_t use_graphs; /* capture token-generation steps into hipGraphs */
+  /* Context-encoding GEMMs (rows > 16) on FP8 weights take per-token dynamically quantized FP8
+   * activations and run on the MX-scaled MFMA at twice the bf16 rate; token generation (HBM-bound)
+   * keeps bf16 activations.  0 = weight-only everywhere. */
+  int32_t prefill_fp8_activations;
 } mi_model_config;
 
 const char* mi_last_error(void);
@@ -154,6 +158,10 @@ int mi_op_untile_weight(const void* tiled, int32_t N, int32_t K, int32_t weight_
 int mi_op_qlinear(const void* x_bf16, int32_t M, const void* w_tiled, const float* scale,
                   const float* bias, int32_t N, int32_t K, int32_t weight_dtype, float* y,
                   int32_t force_path, void* stream);
+/* FP8-activation form (M > 16, fp8 weights, K % 128 == 0): x is quantized per token to e4m3
+ * (scale amax/448) and multiplied on v_mfma_scale_f32_16x16x128_f8f6f4. */
+int mi_op_qlinear_a8(const void* x_bf16, int32_t M, const void* w_tiled, const float* scale,
+                     const float* bias, int32_t N, int32_t K, float* y, void* stream);
 /* y[T, H] bf16 = rmsnorm(x[T, H] fp32) * g */
 int mi_op_rmsnorm(const float* x, const float* g, int32_t T, int32_t H, float eps, void* y_bf16,
                   void* stream);

@@ -35,6 +35,12 @@ its oracle of record (test/e2e/online/online_server_runner.py:95-146).
           stream; bf16 at every GEMM input (post-norm activations, attention
           output, SwiGLU output), bf16 q and bf16 K/V cache; fp32 accumulation,
           fp32 softmax, fp32 logits.
+
+``prefill_fp8_activations`` (with fp8-quantized weights): a linear whose input has MORE THAN
+16 rows and whose K is a multiple of 128 — i.e. the context-encoding GEMMs, never the
+token-generation GEMVs nor the 1-row lm_head — quantizes its bf16 input per token to OCP
+e4m3 (scale = amax/448, RNE) before the contraction, like the device's MX-scaled MFMA path.
+PARITY UNPINNED upstream (no reference test covers quantized outputs); this is the definition.
 """
 
 from __future__ import annotations
@@ -118,9 +124,11 @@ class PagedDecoderOracle:
     platform.py:150-159 / loader.py:806-815)."""
 
     def __init__(self, cfg: DecoderConfig, weights: dict, num_blocks: int, block_size: int,
-                 compute: str = "fp32", quant: dict | None = None):
+                 compute: str = "fp32", quant: dict | None = None, prefill_fp8_activations: bool = False):
         assert compute in ("fp32", "bf16")
         self.cfg, self.compute = cfg, compute
+        self.a8 = bool(prefill_fp8_activations)
+        self.a8_weights: set = set()
         self.block_size, self.num_blocks = block_size, num_blocks
         self.r = _bf16 if compute == "bf16" else (lambda t: t)
         self.quant = quant
@@ -142,6 +150,8 @@ class PagedDecoderOracle:
                 # quantize-at-load from the tensor as handed over (loader.py:238-239)
                 qt, sc = quantize_weight(t, q.get("quantization_dtype", "int8"),
                                          q.get("quantization_type", "per_tensor_symmetric"))
+                if q.get("quantization_dtype") == "f8e4m3" and t.shape[1] % 128 == 0:
+                    self.a8_weights.add(name)
                 t = dequantize_weight(qt, sc)
             elif self.compute == "bf16" and (is_linear or name == "model.embed_tokens.weight"):
                 t = _bf16(t)            # device copies of unquantized matrices are bf16;
@@ -166,6 +176,10 @@ class PagedDecoderOracle:
 
     def _lin(self, x, name, layer=None):
         p = f"model.layers.{layer}." if layer is not None else ""
+        if self.a8 and x.shape[0] > 16 and f"{p}{name}.weight" in self.a8_weights:
+            amax = x.abs().amax(dim=1, keepdim=True)
+            s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+            x = (x / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s
         y = x @ self.w[f"{p}{name}.weight"].t()
         b = self.w.get(f"{p}{name}.bias")
         return y if b is None else y + b

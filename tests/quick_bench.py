@@ -7,6 +7,7 @@ from tests.helpers import prefill_inputs, decode_inputs
 
 wd = sys.argv[1] if len(sys.argv) > 1 else "f8e4m3"
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+A8 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 BS, MAXLEN, NSEQ = 32, 2048, 4
 MB = MAXLEN // BS
 NB = 4096 + 1
@@ -17,7 +18,8 @@ m = NativeModel(num_layers=L, hidden_size=4096, num_heads=32, num_kv_heads=8, he
                 rope_original_max_position=8192, qkv_bias=0, tie_word_embeddings=0,
                 num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
                 weight_dtype=MI_W[wd], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
-                tp_degree=1, tp_rank=0, device_id=0, use_graphs=1, ctx_buckets=[256, 512, 1024, 2048])
+                tp_degree=1, tp_rank=0, device_id=0, use_graphs=1, ctx_buckets=[256, 512, 1024, 2048],
+                prefill_fp8_activations=A8)
 m.init_synthetic_weights(1, 0.02)
 m.finalize()
 print("init s", time.time() - t0, m.kv_stats(), flush=True)

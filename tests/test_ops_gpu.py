@@ -89,6 +89,33 @@ def test_qlinear(lib, wd, M, path, N, K):
     assert err < tol, (err, tol)
 
 
+@pytest.mark.parametrize("M", [17, 128, 200, 300])
+@pytest.mark.parametrize("N,K", [(576, 384), (1024, 4096), (256, 14336)])
+def test_qlinear_fp8_activations(lib, M, N, K):
+    """MX-scaled fp8 x fp8 GEMM: per-token e4m3 activations (amax/448), per-channel e4m3 weights.
+    Products of e4m3 values are exact in fp32, so only the summation order differs."""
+    torch.manual_seed(3)
+    w = torch.randn(N, K) * 0.05
+    x = (torch.randn(M, K) * torch.rand(M, 1) * 4).to(torch.bfloat16)
+    x[1] = 0                                    # all-zero token -> scale 1
+    bias = torch.randn(N) * 0.1
+    tiled, scale = quantize_on_device(lib, w, "f8e4m3", "per_channel_symmetric")
+    wq = dequantize_weight(*quantize_weight(w, "f8e4m3", "per_channel_symmetric"))
+    xf = x.float()
+    amax = xf.abs().amax(1, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    xq = (xf / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+    ref = xq.double() @ wq.double().t() + bias.double()
+    y = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    xd, bd = dev(x), dev(bias)
+    lib.check(lib.load_library().mi_op_qlinear_a8(xd.data_ptr(), M, tiled.data_ptr(), scale.data_ptr(), bd.data_ptr(),
+                                                  N, K, y.data_ptr(), None))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    tol = 2e-5 * ref.abs().max().item() + 1e-5 * (K ** 0.5)
+    assert err < tol, (err, tol)
+
+
 def test_rmsnorm(lib):
     torch.manual_seed(2)
     T, H = 37, 448

@@ -35,7 +35,7 @@ class MiModelConfig(C.Structure):
         ("max_model_len", C.c_int32), ("num_ctx_buckets", C.c_int32), ("ctx_buckets", C.c_int32 * 8),
         ("weight_dtype", C.c_int32), ("quant_type", C.c_int32), ("quantize_lm_head", C.c_int32),
         ("tp_degree", C.c_int32), ("tp_rank", C.c_int32), ("device_id", C.c_int32),
-        ("use_graphs", C.c_int32),
+        ("use_graphs", C.c_int32), ("prefill_fp8_activations", C.c_int32),
     ]
 
 
@@ -73,6 +73,8 @@ _SIGS = {
                                       C.c_void_p]),
     "mi_op_qlinear": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mi_op_qlinear_a8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_void_p, C.c_void_p]),
     "mi_op_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                 C.c_void_p]),
     "mi_op_kv_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

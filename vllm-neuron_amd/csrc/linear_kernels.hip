@@ -36,7 +36,11 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n0, 
 
 template <int EPI>
 __device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_t v) {
-  const float4 sc = *reinterpret_cast<const float4*>(e.scale + n0);
+  float4 sc = *reinterpret_cast<const float4*>(e.scale + n0);
+  if (e.row_scale) {   // FP8 activations: the token's scale multiplies the channel's
+    const float rs = e.row_scale[m];
+    sc.x *= rs; sc.y *= rs; sc.z *= rs; sc.w *= rs;
+  }
   v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
   if (e.bias) {
     const float4 b = *reinterpret_cast<const float4*>(e.bias + n0);
@@ -644,6 +648,122 @@ int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, co
 }
 
 // =====================================================================================
+// GEMM with FP8 activations (context encoding, the MFMA-bound contraction)
+// =====================================================================================
+// y[m, n] = (sum_k q_x[m, k] * q_w[n, k]) * s_w[n] * s_x[m]   both operands OCP e4m3.
+// v_mfma_scale_f32_16x16x128_f8f6f4 with every block scale = 2^0 runs at twice the rate of
+// the bf16 (and of the unscaled fp8) MFMA.  Its lane (g = lane >> 4, r = lane & 15) holds 32
+// bytes of row r: they are taken as the lane's 16 bytes of weight tile 2s and of tile 2s + 1
+// (the contraction order inside an MFMA is free as long as both operands agree), so the
+// weight image is the same one the GEMV streams.  Work-group = 4 waves, tile 256 (n) x 128 (m):
+// wave w owns n-tiles 4w..4w+3 against all 8 m-tiles (128 fp32 accumulators per lane, one wave
+// per SIMD); W fragments come straight from global (every wave reads distinct rows), x8 goes
+// through LDS; the next K-step's operands are fetched into registers under the MFMAs.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+constexpr int kA8BM = 128, kA8BN = 256, kA8BK = 128;
+constexpr int kA8Pitch = kA8BK + 16;   // LDS row pitch in bytes (+16: rows start 4 banks apart)
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
+                                                      const uint8_t* __restrict__ x8, int ldx, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[kA8BM * kA8Pitch];   // 18 KiB
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int m0 = blockIdx.x * kA8BM, nt0 = blockIdx.y * (kA8BN / 16) + wave * 4;
+  const int nks = K / kA8BK;
+  constexpr int kUnit = 0x7f7f7f7f;   // E8M0 block scales: 2^0
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // x staging: 128 rows x 128 B per K-step = 1024 chunks of 16 B, 4 per thread
+  u32x4_t xr[4], wr[4][2], wn[4][2];
+  auto load_x = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+      const int m = min(m0 + row, T - 1);   // rows past T are computed on a copy of the last row, never stored
+      xr[i] = *reinterpret_cast<const u32x4_t*>(x8 + (size_t)m * ldx + ks * kA8BK + ch * 16);
+    }
+  };
+  auto load_w = [&](u32x4_t (&dst)[4][2], int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nt = min(nt0 + i, NT - 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        dst[i][t] = *reinterpret_cast<const u32x4_t*>(W + ((size_t)nt * KT + ks * 2 + t) * 64 + lane);
+    }
+  };
+  load_x(0);
+  load_w(wr, 0);
+  for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<u32x4_t*>(&xs[row * kA8Pitch + ch * 16]) = xr[i];
+    }
+    __syncthreads();
+    if (ks + 1 < nks) {
+      load_x(ks + 1);
+      load_w(wn, ks + 1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const unsigned char* xrow = &xs[(mt * 16 + c) * kA8Pitch + g * 16];
+      const u32x4_t b0 = *reinterpret_cast<const u32x4_t*>(xrow);        // k-tile 2ks,   chunk g
+      const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(xrow + 64);   // k-tile 2ks+1, chunk g
+      const i32x8_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const i32x8_t a = {(int)wr[i][0][0], (int)wr[i][0][1], (int)wr[i][0][2], (int)wr[i][0][3],
+                           (int)wr[i][1][0], (int)wr[i][1][1], (int)wr[i][1][2], (int)wr[i][1][3]};
+        acc[i][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i][mt], 0, 0, 0, kUnit, 0, kUnit);
+      }
+    }
+    __syncthreads();
+    if (ks + 1 < nks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wr[i][0] = wn[i][0];
+        wr[i][1] = wn[i][1];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (nt0 + i >= NT) continue;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + mt * 16 + c;
+      if (m < T) epilogue<EPI>(e, m, (nt0 + i) * 16 + g * 4, acc[i][mt]);
+    }
+  }
+}
+
+bool gemm_a8_supported(const LinearW& w) {
+  return w.wd == MI_W_F8E4M3 && w.K % kA8BK == 0 && w.N % 16 == 0;
+}
+
+int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  MI_CHECK(T >= 1, "gemm_a8: T must be >= 1");
+  MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
+  MI_CHECK(ldx % 16 == 0 && e.row_scale != nullptr, "gemm_a8: x row stride % 16 and a row scale are required");
+  const int NT = w.N / 16, KT = w.K / 64;
+  dim3 grid(ceil_div(T, kA8BM), ceil_div(w.N, kA8BN));
+  const uint4* W = reinterpret_cast<const uint4*>(w.w);
+  if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_a8_kernel<EPI_QKV>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
+  else if (epi == EPI_SWIGLU) hipLaunchKernelGGL((gemm_a8_kernel<EPI_SWIGLU>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
+  else if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_a8_kernel<EPI_RESID>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
+  else hipLaunchKernelGGL((gemm_a8_kernel<EPI_F32>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// =====================================================================================
 // Load-time quantize + tile
 // =====================================================================================
 __global__ void rowmax_kernel(const float* __restrict__ w, int ld, float* __restrict__ rowmax) {
@@ -689,6 +809,52 @@ __device__ __forceinline__ uint32_t f32_to_e4m3fn(float f) {
     code = code > 0x7Eu ? 0x7Eu : code;
   }
   return sign | code;
+}
+
+// bf16 activations -> e4m3 + per-token scale: s = amax / 448 (all-zero row: 1), q = rne(x / s).
+// One work-group per row.
+__global__ __launch_bounds__(256) void rowquant_fp8_kernel(const uint16_t* __restrict__ x, int K, int ldx,
+                                                           uint8_t* __restrict__ x8, float* __restrict__ row_scale) {
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const uint16_t* row = x + (size_t)t * ldx;
+  float amax = 0.f;
+  for (int c8 = tid; c8 < K / 8; c8 += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(row + c8 * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(bf16lo_to_f32(w[k])), fabsf(bf16hi_to_f32(w[k]))));
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1));
+  amax = fmaxf(amax, __shfl_xor(amax, 2));
+  amax = fmaxf(amax, __shfl_xor(amax, 4));
+  amax = fmaxf(amax, __shfl_xor(amax, 8));
+  amax = fmaxf(amax, __shfl_xor(amax, 16));
+  amax = fmaxf(amax, __shfl_xor(amax, 32));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float scale = amax > 0.f ? amax / 448.f : 1.f;
+  if (tid == 0) row_scale[t] = scale;
+  for (int c8 = tid; c8 < K / 8; c8 += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(row + c8 * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fminf(fmaxf(bf16lo_to_f32(w[k]) / scale, -448.f), 448.f);
+      const float b = fminf(fmaxf(bf16hi_to_f32(w[k]) / scale, -448.f), 448.f);
+      o[k >> 1] |= (f32_to_e4m3fn(a) | (f32_to_e4m3fn(b) << 8)) << (16 * (k & 1));
+    }
+    *reinterpret_cast<uint2*>(x8 + (size_t)t * K + c8 * 8) = make_uint2(o[0], o[1]);
+  }
+}
+
+int launch_rowquant_fp8(const uint16_t* x, int T, int K, int ldx, uint8_t* x8, float* row_scale, hipStream_t s) {
+  MI_CHECK(K % 8 == 0 && ldx % 8 == 0, "rowquant: K and the row stride must be multiples of 8");
+  hipLaunchKernelGGL(rowquant_fp8_kernel, dim3(T), dim3(256), 0, s, x, K, ldx, x8, row_scale);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
 }
 
 __device__ __forceinline__ int dst_to_src_row(const QuantJob& j, int r) {

@@ -92,6 +92,8 @@ struct mi_ctx {
   float* resid[2] = {nullptr, nullptr};
   float* partial = nullptr;
   uint16_t *xn = nullptr, *qbuf = nullptr, *attn_out = nullptr, *act = nullptr;
+  uint8_t* x8 = nullptr;        // FP8-activation GEMM input [rows, K]
+  float* x8_scale = nullptr;    // its per-token scales [rows]
   float* logits = nullptr;      // [max_num_seqs, V_l]
   float* logits_all = nullptr;  // [tp, max_num_seqs, V_l] (tp > 1)
   void* attn_scratch = nullptr;
@@ -186,6 +188,15 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
     MI_TRY(launch_norm_rows(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->xn, c->stream));
     x = c->xn;
     ldx = L.K;
+  }
+  if (c->cfg.prefill_fp8_activations && gemm_a8_supported(L.view())) {
+    {
+      Scope sc(c, MI_K_OTHER);
+      MI_TRY(launch_rowquant_fp8(x, rows, L.K, ldx, c->x8, c->x8_scale, c->stream));
+    }
+    e.row_scale = c->x8_scale;
+    Scope sc(c, MI_K_GEMM);
+    return launch_gemm_a8(L.view(), rows, c->x8, L.K, epi, e, c->stream);
   }
   Scope sc(c, MI_K_GEMM);
   return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
@@ -560,7 +571,7 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx};
+                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx, c->x8, c->x8_scale};
   for (void* p : ptrs) hipFree(p);
   void* hptrs[] = {c->h_ids, c->h_pos, c->h_slots, c->h_bt, c->h_ctx, c->h_logits};
   for (void* p : hptrs) if (p) hipHostFree(p);
@@ -687,6 +698,10 @@ int mi_finalize(mi_ctx* c) {
   MI_TRY(dmalloc(&c->qbuf, R * c->q_dim, ws));
   MI_TRY(dmalloc(&c->attn_out, R * c->q_dim, ws));
   MI_TRY(dmalloc(&c->act, R * c->I_l, ws));
+  if (k.prefill_fp8_activations) {
+    MI_TRY(dmalloc(&c->x8, R * std::max(std::max(c->H, c->I_l), c->q_dim), ws));
+    MI_TRY(dmalloc(&c->x8_scale, R, ws));
+  }
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
   if (c->comm) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
   MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
@@ -893,6 +908,27 @@ int mi_op_qlinear(const void* x, int32_t M, const void* w_tiled, const float* sc
   const bool gemv = force_path == 1 || (force_path == 0 && gemv_fits(M, K));
   if (gemv) return launch_gemv(W, M, PRO_BF16, p, EPI_F32, e, (hipStream_t)stream);
   return launch_gemm(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
+}
+int mi_op_qlinear_a8(const void* x, int32_t M, const void* w_tiled, const float* scale, const float* bias, int32_t N,
+                     int32_t K, float* y, void* stream) {
+  MI_CHECK(x && w_tiled && scale && y, "null argument");
+  LinearW W{w_tiled, N, K, MI_W_F8E4M3};
+  MI_CHECK(gemm_a8_supported(W), "qlinear_a8: needs K % 128 == 0 and N % 16 == 0");
+  uint8_t* x8 = nullptr;
+  float* xs = nullptr;
+  MI_HIP(hipMalloc(reinterpret_cast<void**>(&x8), (size_t)M * K));
+  MI_HIP(hipMalloc(reinterpret_cast<void**>(&xs), (size_t)M * 4));
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_rowquant_fp8(reinterpret_cast<const uint16_t*>(x), M, K, K, x8, xs, s);
+  if (rc == MI_OK) {
+    EpiArgs e{};
+    e.scale = scale; e.bias = bias; e.out_f32 = y; e.ld_out = N; e.row_scale = xs;
+    rc = launch_gemm_a8(W, M, x8, K, EPI_F32, e, s);
+  }
+  hipStreamSynchronize(s);
+  hipFree(x8);
+  hipFree(xs);
+  return rc;
 }
 int mi_op_rmsnorm(const float* x, const float* g, int32_t T, int32_t H, float eps, void* y, void* stream) {
   MI_CHECK(x && g && y, "null argument");

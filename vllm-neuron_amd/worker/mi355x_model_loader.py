@@ -15,6 +15,8 @@ working).  Extra keys understood here:
   synthetic_weights          {"seed","std"} random weights generated on the device (bench)
   state_dict                 dict[str, Tensor] in-memory HF-named weights (tests)
   use_graphs                 bool           hipGraph capture of token-generation steps
+  prefill_fp8_activations    bool           context-encoding GEMMs on FP8 weights quantize their bf16
+                                            inputs per token to e4m3 and run on the MX-scaled MFMA
 """
 
 from __future__ import annotations
@@ -186,6 +188,7 @@ class MI355XCausalLM(MI355XModelBase):
             device_id=int(kwargs.get("device_id", 0)),
             # collectives are launched eagerly for now: graphs only when a single GPU runs the step
             use_graphs=int(cfg.get("use_graphs", int(cfg["tp_degree"]) == 1)),
+            prefill_fp8_activations=int(bool(cfg.get("prefill_fp8_activations", False))),
             **geo)
         if cfg["tp_degree"] > 1:
             uid = kwargs.get("tp_unique_id")
