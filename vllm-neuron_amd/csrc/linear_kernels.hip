@@ -663,14 +663,21 @@ typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 constexpr int kA8BM = 128, kA8BN = 256, kA8BK = 128;
 constexpr int kA8Pitch = kA8BK + 16;   // LDS row pitch in bytes (+16: rows start 4 banks apart)
 
-template <int EPI>
+// SPLIT: grid.z K-slices each write their raw fp32 accumulators to slab[z][m][n]; splitk_reduce
+// sums the slabs in slice order (deterministic) and applies the epilogue.  Used when a short
+// prompt leaves the (m-tile x n-tile) grid too small to pull the weights at HBM rate.
+template <int EPI, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
-                                                      const uint8_t* __restrict__ x8, int ldx, EpiArgs e) {
+                                                      const uint8_t* __restrict__ x8, int ldx, EpiArgs e,
+                                                      float* __restrict__ slab) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[kA8BM * kA8Pitch];   // 18 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   const int m0 = blockIdx.x * kA8BM, nt0 = blockIdx.y * (kA8BN / 16) + wave * 4;
-  const int nks = K / kA8BK;
+  const int nks_all = K / kA8BK;
+  const int ks_per = SPLIT ? ceil_div(nks_all, (int)gridDim.z) : nks_all;
+  const int ks_beg = SPLIT ? (int)blockIdx.z * ks_per : 0;
+  const int nks = min(ks_beg + ks_per, nks_all);   // exclusive end of this slice
   constexpr int kUnit = 0x7f7f7f7f;   // E8M0 block scales: 2^0
 
   f32x4_t acc[4][8];
@@ -698,9 +705,11 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
         dst[i][t] = *reinterpret_cast<const u32x4_t*>(W + ((size_t)nt * KT + ks * 2 + t) * 64 + lane);
     }
   };
-  load_x(0);
-  load_w(wr, 0);
-  for (int ks = 0; ks < nks; ++ks) {
+  if (ks_beg < nks) {
+    load_x(ks_beg);
+    load_w(wr, ks_beg);
+  }
+  for (int ks = ks_beg; ks < nks; ++ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
@@ -739,26 +748,65 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const int m = m0 + mt * 16 + c;
-      if (m < T) epilogue<EPI>(e, m, (nt0 + i) * 16 + g * 4, acc[i][mt]);
+      if (m >= T) continue;
+      const int n0 = (nt0 + i) * 16 + g * 4;
+      if constexpr (SPLIT) {
+        *reinterpret_cast<float4*>(slab + ((size_t)blockIdx.z * T + m) * (NT * 16) + n0) =
+            make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+      } else {
+        epilogue<EPI>(e, m, n0, acc[i][mt]);
+      }
     }
   }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int KS, int T, int N, EpiArgs e) {
+  const int q = blockIdx.x * 256 + threadIdx.x;      // one (m, 4 consecutive n) per thread
+  const int nq = N >> 2;
+  if (q >= T * nq) return;
+  const int m = q / nq, n0 = (q - m * nq) * 4;
+  f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < KS; ++z) {
+    const float4 p = *reinterpret_cast<const float4*>(slab + ((size_t)z * T + m) * N + n0);
+    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+  }
+  epilogue<EPI>(e, m, n0, v);
 }
 
 bool gemm_a8_supported(const LinearW& w) {
   return w.wd == MI_W_F8E4M3 && w.K % kA8BK == 0 && w.N % 16 == 0;
 }
 
-int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                   float* splitk_ws, size_t splitk_ws_bytes) {
   MI_CHECK(T >= 1, "gemm_a8: T must be >= 1");
   MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
   MI_CHECK(ldx % 16 == 0 && e.row_scale != nullptr, "gemm_a8: x row stride % 16 and a row scale are required");
-  const int NT = w.N / 16, KT = w.K / 64;
-  dim3 grid(ceil_div(T, kA8BM), ceil_div(w.N, kA8BN));
+  const int NT = w.N / 16, KT = w.K / 64, nks = w.K / kA8BK;
+  const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(w.N, kA8BN);
+  // K-split only when the tile grid cannot occupy the chip and the slabs stay small
+  int KS = 1;
+  if (splitk_ws && mtiles * ntiles < 192) {
+    KS = min(min(8, nks), ceil_div(256, mtiles * ntiles));
+    while (KS > 1 && (size_t)KS * T * w.N * sizeof(float) > splitk_ws_bytes) --KS;
+  }
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
-  if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_a8_kernel<EPI_QKV>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
-  else if (epi == EPI_SWIGLU) hipLaunchKernelGGL((gemm_a8_kernel<EPI_SWIGLU>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
-  else if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_a8_kernel<EPI_RESID>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
-  else hipLaunchKernelGGL((gemm_a8_kernel<EPI_F32>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e);
+  dim3 grid(mtiles, ntiles, KS);
+#define MI_A8(EPI_) \
+  do { \
+    if (KS == 1) { \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
+    } else { \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
+      hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+    } \
+  } while (0)
+  if (epi == EPI_QKV) MI_A8(EPI_QKV);
+  else if (epi == EPI_SWIGLU) MI_A8(EPI_SWIGLU);
+  else if (epi == EPI_RESID) MI_A8(EPI_RESID);
+  else MI_A8(EPI_F32);
+#undef MI_A8
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -94,6 +94,8 @@ struct mi_ctx {
   uint16_t *xn = nullptr, *qbuf = nullptr, *attn_out = nullptr, *act = nullptr;
   uint8_t* x8 = nullptr;        // FP8-activation GEMM input [rows, K]
   float* x8_scale = nullptr;    // its per-token scales [rows]
+  float* splitk_ws = nullptr;   // fp32 K-split slabs of short-prompt GEMMs
+  size_t splitk_ws_bytes = 0;
   float* logits = nullptr;      // [max_num_seqs, V_l]
   float* logits_all = nullptr;  // [tp, max_num_seqs, V_l] (tp > 1)
   void* attn_scratch = nullptr;
@@ -196,7 +198,7 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
     }
     e.row_scale = c->x8_scale;
     Scope sc(c, MI_K_GEMM);
-    return launch_gemm_a8(L.view(), rows, c->x8, L.K, epi, e, c->stream);
+    return launch_gemm_a8(L.view(), rows, c->x8, L.K, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
   }
   Scope sc(c, MI_K_GEMM);
   return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
@@ -571,7 +573,7 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx, c->x8, c->x8_scale};
+                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx, c->x8, c->x8_scale, c->splitk_ws};
   for (void* p : ptrs) hipFree(p);
   void* hptrs[] = {c->h_ids, c->h_pos, c->h_slots, c->h_bt, c->h_ctx, c->h_logits};
   for (void* p : hptrs) if (p) hipHostFree(p);
@@ -701,6 +703,8 @@ int mi_finalize(mi_ctx* c) {
   if (k.prefill_fp8_activations) {
     MI_TRY(dmalloc(&c->x8, R * std::max(std::max(c->H, c->I_l), c->q_dim), ws));
     MI_TRY(dmalloc(&c->x8_scale, R, ws));
+    c->splitk_ws_bytes = (size_t)64 << 20;
+    MI_TRY(dmalloc(&c->splitk_ws, c->splitk_ws_bytes / 4, ws));
   }
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
   if (c->comm) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
