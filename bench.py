@@ -177,6 +177,8 @@ def main():
             out = eng.generate([prompt], SamplingParams(temperature=0.0, max_tokens=1))[0]
             samples.append(out.ttft_s * 1e3)
         ttft[str(bucket)] = round(statistics.median(samples[1:]), 3)
+        if rank == 0:
+            print(f"[bench] ttft bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
 
     # ---- decode: B sequences at context DECODE_CTX ------------------------------------------
     from tests.helpers import decode_inputs

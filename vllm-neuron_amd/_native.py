@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmi355x_vllm.so")
+# MI355X_VLLM_LIB points at another build of the same library (A/B measurements)
+LIB_PATH = os.environ.get("MI355X_VLLM_LIB") or os.path.join(_HERE, "csrc", "libmi355x_vllm.so")
 
 MI_F32, MI_BF16 = 0, 1
 MI_W = {"bfloat16": 0, "bf16": 0, None: 0, "f8e4m3": 1, "fp8": 1, "int8": 2}

@@ -10,6 +10,7 @@ per step — so the same plugin code paths are exercised and timed.
 
 from __future__ import annotations
 
+import gc
 import time
 from dataclasses import dataclass, field
 
@@ -68,6 +69,12 @@ class MI355XEngine:
         self.scheduler = ContinuousBatchingMI355XScheduler(cfg, KVCacheConfig(num_blocks=num_blocks))
         self.outputs: dict[str, RequestOutput] = {}
         self._next_id = 0
+        # What vLLM's engine core does once start-up is over: move everything allocated so far
+        # (torch, the model wrappers, config objects) out of the collector's reach, so a full
+        # collection in the serving loop does not walk it (measured here: 40-80 ms stalls on
+        # every third request, i.e. several TTFTs).
+        gc.collect()
+        gc.freeze()
 
     def add_request(self, prompt_token_ids, sampling_params: SamplingParams | None = None, eos_token_id=None,
                     request_id: str | None = None) -> str:

@@ -47,9 +47,33 @@ class MI355XWorker(WorkerBase):
 
     def init_device(self) -> None:
         self.init_distributed_environment()
+        self._bound_host_threads()
         set_random_seed(self.model_config.seed)
         uid = self._exchange_tp_unique_id() if self.tp_size > 1 else None
         self.model_runner = self.get_mi355x_model_runner(self.vllm_config, self.device, uid)
+
+    def _bound_host_threads(self) -> None:
+        """Keep torch's CPU pool (the sampler's argmax / top-k over [B, vocab]) inside this
+        process's CPU share.  torch sizes its pool from the machine's core count; inside a
+        container with a CFS quota (16 of 256 cores on the benchmark boxes) the idle workers'
+        spin-waits exhaust the quota and the kernel parks the WHOLE process for the rest of
+        the 100 ms period -- measured as 40-80 ms added to every third TTFT."""
+        import os
+        import torch
+        share = len(os.sched_getaffinity(0))
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as f:
+                quota, period = f.read().split()[:2]
+            if quota != "max":
+                share = min(share, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        share = max(1, share // max(1, self.tp_size))
+        want = min(share, 8)
+        if torch.get_num_threads() > want:
+            logger.info("bounding torch CPU threads %d -> %d (cpu share %d)", torch.get_num_threads(),
+                        want, share)
+            torch.set_num_threads(want)
 
     def _exchange_tp_unique_id(self) -> bytes:
         """Rank 0 asks RCCL for a unique id; torch.distributed carries the 128 bytes."""
