@@ -158,9 +158,10 @@ def test_kv_write(lib):
 
 
 @pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 8, 1), (64, 7, 1), (128, 4, 4), (128, 2, 1)])
-@pytest.mark.parametrize("ctx", [[1, 31, 32, 33], [700, 5, 1024, 257], [2040]])
+@pytest.mark.parametrize("ctx", [[1, 31, 32, 33], [700, 5, 1024, 257], [2040], [4100, 63, 5000]])
 def test_paged_attn_decode(lib, hd, nh, nkv, ctx):
-    bs, MB = 32, 64
+    # block-table widths up to 4096 tokens take the one-launch form, wider ones the split + combine form
+    bs, MB = 32, (64 if max(ctx) <= 2048 else 160)
     B = len(ctx)
     nb = 1 + B * MB
     k, v = _make_pool(nb, bs, nkv, hd, 4)

@@ -1,13 +1,14 @@
 // Paged-KV attention kernels for gfx950.  See attn_kernels.h for the contract.
 //
 // Token generation (attn_decode_kernel): HBM-bound.  One work-group per
-// (context split, kv head, sequence); its 4 waves walk 32-token tiles of the sequence's
-// blocks.  A tile row (one token, hd bf16) is read by hd/8 adjacent lanes as one 16-byte
-// load each, so a wave-instruction moves 1 KiB of contiguous pool memory; 2 * 32*hd*2 bytes
-// (K and V tile) are in flight per wave.  q.k uses v_dot2c_f32_bf16 and a DPP sum over the
-// row's lanes; every lane group keeps its own online-softmax state, merged once at the end
-// (wave shuffles, then LDS across the 4 waves).  Splits are merged by attn_combine_kernel in
-// a fixed order (deterministic).
+// (context split, kv head, sequence); its waves walk 32-token tiles of the sequence's blocks,
+// two tiles in flight per wave.  The query heads of the kv group are the columns of MFMA tiles
+// (S^T = K.Q^T from K fragments loaded straight from the pool; O^T += V^T.P^T with V parked in a
+// wave-private LDS tile and read transposed), so the arithmetic per byte is a few hundred
+// cycles per 16 KiB tile -- the VALU dot-product form this replaced cost ~3000.  With fewer
+// (sequence, kv head) pairs than CUs the context is split over work-groups and the splits are
+// merged by attn_combine_kernel in a fixed order (deterministic); otherwise one work-group
+// covers the whole sequence.
 //
 // Context encoding (attn_prefill_kernel): MFMA flash attention over the same pool.  Scores
 // are computed transposed (S^T = K.Q^T) so the accumulator registers ARE the B operand of
@@ -26,141 +27,194 @@ __device__ __forceinline__ float sexp2(float x, float m) {
 // =====================================================================================
 // token generation
 // =====================================================================================
-template <int HD, int GP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// NW waves per work-group.  FINAL: the work-group covers the whole context of its (sequence, kv
+// head) and writes the bf16 output itself (grid (1, nkv, B)); otherwise it covers context split
+// blockIdx.x of NS and leaves (o, m, l) partials for attn_combine_kernel.
+//
+// A wave walks 32-token tiles.  The G <= 16 query heads of the kv group are the 16 columns of the
+// MFMA tiles (the idle columns cost nothing: the kernel is bound by bytes, not by the matrix core):
+//     S^T[token][head]  = K_tile . Q^T             2 x HD/32 MFMA 16x16x32 (two 16-token halves)
+//     O^T[d][head]     += V_tile^T . P^T           HD/16 MFMA 16x16x32, k = the tile's 32 tokens
+// K goes from the pool straight into A fragments (lane (g, c): token c, 16 B of the row).  V is
+// read as whole rows, parked row-major in a wave-private LDS tile and picked up transposed by
+// ds_read_b64_tr_b16.  The P.V k-slot (g, j) is bound to token (j < 4 ? 4g + j : 16 + 4g + j - 4),
+// which is where the two S^T accumulators already hold that token's score, so the exponentiated
+// scores are the B operand as they stand.
+// Every wave keeps TWO tiles in flight (the next tile is requested before the current one is
+// consumed); a tile past the wave's range is requested as one harmless line of the null block, so
+// the loop has no predicated loads.  Rows of the last tile beyond the context are masked by score;
+// the pool must not hold NaN/Inf there (the library zero-fills it and only ever writes finite values).
+template <int HD, int NW, bool FINAL>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpool, const uint16_t* __restrict__ vpool,
     int bs, const int32_t* __restrict__ block_table, int MB, const int32_t* __restrict__ ctx_lens,
-    int nh, int nkv, int G, int NS, float* __restrict__ o_part, float* __restrict__ ml_part, float scale_log2e) {
-  constexpr int LPR = HD / 8;    // lanes per token row
-  constexpr int TPI = 64 / LPR;  // tokens per wave-instruction
-  constexpr int NI = 32 / TPI;   // loads per 32-token tile
-  __shared__ float sm_o[4][GP][HD];
-  __shared__ float sm_ml[4][GP][2];
+    int nh, int nkv, int G, int NS, float* __restrict__ o_part, float* __restrict__ ml_part,
+    uint16_t* __restrict__ out, float scale_log2e) {
+  constexpr int KP = HD + 8;        // LDS row pitch (elements)
+  constexpr int CPR = HD / 8;       // 16-byte chunks per row
+  constexpr int KS = HD / 32, DN = HD / 16;
+  constexpr int NV = 32 * CPR / 64; // 16-byte V loads per lane per tile
+  constexpr int VT = 32 * KP;       // elements of one wave's V tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  uint16_t* Vs = reinterpret_cast<uint16_t*>(dsm);                       // [NW][32][KP] bf16
+  float* sm_ml = reinterpret_cast<float*>(dsm + (size_t)NW * VT * 2);    // [NW][16][2]
 
   const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tg = lane / LPR, dl = lane % LPR;
+  const int g = lane >> 4, c = lane & 15;
   const int ctx = ctx_lens[b];
   const int nt = ceil_div(ctx, 32), tps = ceil_div(nt, NS);
   const int t_beg = split * tps, t_end = min(nt, t_beg + tps);
+  uint16_t* Vw = Vs + wave * VT;
 
-  uint4 qp[GP];
+  u32x4_t kA[2 * KS], vA[NV], kB[2 * KS], vB[NV];
+  auto issue = [&](u32x4_t (&kr)[2 * KS], u32x4_t (&vr)[NV], int tt) {
+    const bool live = tt < t_end;
+    const int tok0 = live ? tt * 32 : 0;
+    const int blk = live ? block_table[(size_t)b * MB + tok0 / bs] : 0;
+    const size_t row0 = live ? ((size_t)blk * nkv + kvh) * bs + (tok0 % bs) : 0;
+    // K fragment (u, ks): token 16u + c, dims 32 ks + 8 g ..
+    const size_t kbase = live ? (row0 + c) * HD + g * 8 : 0;
+    const size_t ku = live ? (size_t)16 * HD : 0, kk = live ? 32 : 0;
 #pragma unroll
-  for (int h = 0; h < GP; ++h)
-    qp[h] = (h < G) ? *reinterpret_cast<const uint4*>(q + ((size_t)b * nh + kvh * G + h) * HD + dl * 8)
-                    : make_uint4(0, 0, 0, 0);
-  float m[GP], l[GP], o[GP][8];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-  for (int h = 0; h < GP; ++h) {
-    m[h] = -INFINITY;
-    l[h] = 0.f;
+      for (int ks = 0; ks < KS; ++ks)
+        kr[u * KS + ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kpool + kbase + u * ku + ks * kk));
+    // V rows: lane-linear 16-byte chunks (whole rows per instruction)
+    const size_t vbase = live ? row0 * HD + lane * 8 : 0;
+    const size_t vi = live ? 64 * 8 : 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[h][e] = 0.f;
-  }
+    for (int i = 0; i < NV; ++i) vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vpool + vbase + i * vi));
+  };
+  issue(kA, vA, t_beg + wave);
 
-  for (int tt = t_beg + wave; tt < t_end; tt += 4) {
+  u32x4_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = (c < G) ? *reinterpret_cast<const u32x4_t*>(q + ((size_t)b * nh + kvh * G + c) * HD + ks * 32 + g * 8)
+                     : u32x4_t{0, 0, 0, 0};
+  f32x4_t acc[DN];
+#pragma unroll
+  for (int dn = 0; dn < DN; ++dn) acc[dn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float mrow = -INFINITY, lrow = 0.f;   // head c: running max (same on its 4 lanes), this lane's share of the sum
+  const int tr_row = (lane & 15) >> 2, tr_col = (lane & 3) * 4;
+
+  auto update = [&](const u32x4_t (&kr)[2 * KS], const u32x4_t (&vr)[NV], int tt) {
+    // park V (the previous tile's transposed reads are complete: their values fed MFMAs already)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = lane + 64 * i;
+      *reinterpret_cast<u32x4_t*>(&Vw[(idx / CPR) * KP + (idx % CPR) * 8]) = vr[i];
+    }
+    asm volatile("" ::: "memory");   // LDS ops of one wave execute in order; keep the compiler from reordering them
+    f32x4_t st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4_t kw = kr[u * KS + ks], qw = qf[ks];
+        st[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kw), __builtin_bit_cast(bf16x8_t, qw), st[u], 0, 0, 0);
+      }
+    }
+    s16x4_t vlo[DN], vhi[DN];
+#pragma unroll
+    for (int dn = 0; dn < DN; ++dn) {
+      const uint16_t* r0 = &Vw[(4 * g + tr_row) * KP + 16 * dn + tr_col];
+      vlo[dn] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)r0);
+      vhi[dn] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(r0 + 16 * KP));
+    }
     const int tok0 = tt * 32;
-    const int blk = block_table[(size_t)b * MB + tok0 / bs];
-    const size_t base = (((size_t)blk * nkv + kvh) * bs + (tok0 % bs)) * HD + dl * 8;
-    uint4 kr[NI], vr[NI];
+    float pv[8];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) kr[i] = *reinterpret_cast<const uint4*>(kpool + base + (size_t)(i * TPI + tg) * HD);
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) vr[i] = *reinterpret_cast<const uint4*>(vpool + base + (size_t)(i * TPI + tg) * HD);
+      for (int i = 0; i < 4; ++i) {
+        float sv = st[u][i] * scale_log2e;
+        if (tok0 + 16 * u + 4 * g + i >= ctx) sv = -INFINITY;
+        pv[4 * u + i] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));       // finite: a processed tile has at least one live token
+    const float mn = fmaxf(mrow, mx);
+    const float alpha = sexp2(mrow, mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pv[k] = sexp2(pv[k], mn);
+      ps += pv[k];
+    }
+    const bool moved = mn != mrow;
+    mrow = mn;
+    lrow = lrow * alpha + ps;
+    union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk.w[k] = pack_bf16x2(pv[2 * k], pv[2 * k + 1]);
+    if (__any(moved)) {
+#pragma unroll
+      for (int dn = 0; dn < DN; ++dn) {
+        acc[dn][0] *= alpha; acc[dn][1] *= alpha; acc[dn][2] *= alpha; acc[dn][3] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int dn = 0; dn < DN; ++dn) {
+      const s16x4_t lo = vlo[dn], hi = vhi[dn];
+      const bf16x8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      acc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pk.v, acc[dn], 0, 0, 0);
+    }
+  };
 
-    float p[NI][GP];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const bool valid = tok0 + i * TPI + tg < ctx;
-#pragma unroll
-      for (int h = 0; h < GP; ++h) {
-        float s = 0.f;
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kr[i].x), __builtin_bit_cast(bf16x2_t, qp[h].x), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kr[i].y), __builtin_bit_cast(bf16x2_t, qp[h].y), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kr[i].z), __builtin_bit_cast(bf16x2_t, qp[h].z), s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kr[i].w), __builtin_bit_cast(bf16x2_t, qp[h].w), s, false);
-        s = group_sum<LPR>(s);
-        p[i][h] = valid ? s * scale_log2e : -INFINITY;
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < GP; ++h) {
-      float mx = p[0][h];
-#pragma unroll
-      for (int i = 1; i < NI; ++i) mx = fmaxf(mx, p[i][h]);
-      const float mn = fmaxf(m[h], mx);
-      const float alpha = sexp2(m[h], mn);  // mn == -inf only if m[h] == -inf -> 0, state is all-zero anyway
-      float ps = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        p[i][h] = sexp2(p[i][h], mn);
-        ps += p[i][h];
-      }
-      l[h] = l[h] * alpha + ps;
-      m[h] = mn;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[h][e] *= alpha;
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float vf[8];
-      vf[0] = bf16lo_to_f32(vr[i].x); vf[1] = bf16hi_to_f32(vr[i].x);
-      vf[2] = bf16lo_to_f32(vr[i].y); vf[3] = bf16hi_to_f32(vr[i].y);
-      vf[4] = bf16lo_to_f32(vr[i].z); vf[5] = bf16hi_to_f32(vr[i].z);
-      vf[6] = bf16lo_to_f32(vr[i].w); vf[7] = bf16hi_to_f32(vr[i].w);
-#pragma unroll
-      for (int h = 0; h < GP; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[h][e] += p[i][h] * vf[e];
-    }
+  for (int tt = t_beg + wave; tt < t_end; tt += 2 * NW) {
+    issue(kB, vB, tt + NW);
+    update(kA, vA, tt);
+    issue(kA, vA, tt + 2 * NW);
+    if (tt + NW < t_end) update(kB, vB, tt + NW);
   }
 
-  // merge the TPI lane groups of this wave
+  // ---- merge the waves: O^T / m / l of wave w go to its own (now idle) LDS tile --------------
+  lrow += __shfl_xor(lrow, 16);
+  lrow += __shfl_xor(lrow, 32);
+  asm volatile("" ::: "memory");
+  float* so = reinterpret_cast<float*>(Vw);            // [16 heads][HD] f32 = 8 KiB at HD 128 <= the tile
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-    for (int h = 0; h < GP; ++h) {
-      const float mo = __shfl_xor(m[h], off), lo = __shfl_xor(l[h], off);
-      const float mn = fmaxf(m[h], mo);
-      const float a = sexp2(m[h], mn), bb = sexp2(mo, mn);
-      l[h] = l[h] * a + lo * bb;
-      m[h] = mn;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * a + __shfl_xor(o[h][e], off) * bb;
-    }
-  }
-  if (tg == 0) {
-#pragma unroll
-    for (int h = 0; h < GP; ++h) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sm_o[wave][h][dl * 8 + e] = o[h][e];
-      if (dl == 0) {
-        sm_ml[wave][h][0] = m[h];
-        sm_ml[wave][h][1] = l[h];
-      }
-    }
+  for (int dn = 0; dn < DN; ++dn) *reinterpret_cast<f32x4_t*>(&so[c * HD + 16 * dn + 4 * g]) = acc[dn];
+  if (g == 0) {
+    sm_ml[(wave * 16 + c) * 2] = mrow;
+    sm_ml[(wave * 16 + c) * 2 + 1] = lrow;
   }
   __syncthreads();
-  for (int idx = tid; idx < G * HD; idx += 256) {
+  for (int idx = tid; idx < G * HD; idx += NW * 64) {
     const int h = idx / HD, d = idx % HD;
-    float M = sm_ml[0][h][0];
+    float M = sm_ml[h * 2];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_ml[w][h][0]);
-    float acc = 0.f, L = 0.f;
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, sm_ml[(w * 16 + h) * 2]);
+    float o = 0.f, L = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float f = sexp2(sm_ml[w][h][0], M);
-      acc += f * sm_o[w][h][d];
-      L += f * sm_ml[w][h][1];
+    for (int w = 0; w < NW; ++w) {  // wave order: deterministic
+      const float f = sexp2(sm_ml[(w * 16 + h) * 2], M);
+      o += f * reinterpret_cast<const float*>(Vs + w * VT)[h * HD + d];
+      L += f * sm_ml[(w * 16 + h) * 2 + 1];
     }
-    const size_t row = ((size_t)b * nh + kvh * G + h) * NS + split;
-    o_part[row * HD + d] = acc;
-    if (d == 0) {
-      ml_part[row * 2] = M;
-      ml_part[row * 2 + 1] = L;
+    if constexpr (FINAL) {
+      out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(o / L);
+    } else {
+      const size_t row = ((size_t)b * nh + kvh * G + h) * NS + split;
+      o_part[row * HD + d] = o;
+      if (d == 0) {
+        ml_part[row * 2] = M;
+        ml_part[row * 2 + 1] = L;
+      }
     }
   }
 }
+template <int HD, int NW>
+constexpr size_t attn_decode_lds() { return (size_t)NW * 32 * (HD + 8) * 2 + (size_t)NW * 16 * 2 * sizeof(float); }
 
 // Merge the context splits of one (sequence, head) in split order.  All partials are
 // fetched before the first use (kAttnMaxSplits is a compile-time bound), so the kernel is
@@ -200,7 +254,7 @@ size_t attn_scratch_bytes(int B, int nh, int hd) {
   return (size_t)B * nh * kAttnMaxSplits * (hd + 2) * sizeof(float);
 }
 
-template <int HD, int GP>
+template <int HD>
 static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int bs,
                            const int32_t* bt, int MB, const int32_t* ctx, int B, int nh, int nkv,
                            uint16_t* out, void* scratch, hipStream_t s) {
@@ -208,9 +262,27 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
   float* o_part = reinterpret_cast<float*>(scratch);
   float* ml_part = o_part + (size_t)B * nh * kAttnMaxSplits * HD;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-  hipLaunchKernelGGL((attn_decode_kernel<HD, GP>), dim3(NS, nkv, B), dim3(256), 0, s, q, kpool, vpool, bs, bt,
-                     MB, ctx, nh, nkv, G, NS, o_part, ml_part, scale_log2e);
-  hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(nh, B), dim3(HD), 0, s, o_part, ml_part, NS, nh, out);
+  constexpr size_t lds8 = attn_decode_lds<HD, 8>(), lds4 = attn_decode_lds<HD, 4>();
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<HD, 8, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<HD, 4, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+    attr_set = true;
+  }
+  if (NS == 1) {
+    // Enough (sequence, kv head) pairs to fill the chip: one launch, no partials.  (Measured: a
+    // single CU sustains only ~32 GB/s from HBM however many loads its waves keep in flight, so
+    // a short grid must split the context over CUs -- the one-launch form at B x nkv = 32 took
+    // 16 us per 1k tokens of context against 8 + 5 us for split + combine.)
+    hipLaunchKernelGGL((attn_decode_kernel<HD, 8, true>), dim3(1, nkv, B), dim3(512), lds8, s, q,
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false>), dim3(NS, nkv, B), dim3(256), lds4, s, q,
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e);
+    hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(nh, B), dim3(HD), 0, s, o_part, ml_part, NS, nh, out);
+  }
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -219,22 +291,10 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
                        const int32_t* block_table, int MB, const int32_t* ctx_lens, int B, int nh,
                        int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
-  MI_CHECK(nh % nkv == 0 && nh / nkv <= 8, "attention: q heads per kv head must be 1..8");
+  MI_CHECK(nh % nkv == 0 && nh / nkv <= 16, "attention: q heads per kv head must be 1..16");
   MI_CHECK(block_size % 32 == 0, "attention: block_size must be a multiple of 32");
-  const int G = nh / nkv;
-#define MI_DEC(HD_, GP_) return launch_decode_t<HD_, GP_>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s)
-  if (hd == 128) {
-    if (G <= 1) MI_DEC(128, 1);
-    if (G <= 2) MI_DEC(128, 2);
-    if (G <= 4) MI_DEC(128, 4);
-    MI_DEC(128, 8);
-  } else {
-    if (G <= 1) MI_DEC(64, 1);
-    if (G <= 2) MI_DEC(64, 2);
-    if (G <= 4) MI_DEC(64, 4);
-    MI_DEC(64, 8);
-  }
-#undef MI_DEC
+  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s);
+  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s);
 }
 
 // =====================================================================================
@@ -250,7 +310,6 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
 // exponentiated accumulators are the B operand as they stand (no LDS round trip for P).  V stays
 // row-major in LDS; its transposed A fragments come from ds_read_b64_tr_b16 (4 keys x 16 dims
 // per 16-lane group).  Next tile's K/V are prefetched into registers under the MFMAs.
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 constexpr int kPrefillMaxBlocks = 2048;
 
 template <int HD, int WAVES>

@@ -301,6 +301,31 @@ __device__ __forceinline__ void gemv_stage_late(const ProArgs& p, int M, int K, 
   }
 }
 
+// Phase timeline of the decode GEMVs (dev builds only: -DMI_TRACE, see tests/trace_gemv.py).
+// Wave 0 of every work-group stamps the 100 MHz wall clock at fixed points into
+// g_trace_buf[launch % kTraceLaunches][block][stamp]; launches are numbered by a device counter.
+#ifdef MI_TRACE
+constexpr int kTraceLaunches = 160, kTraceBlocks = 512, kTraceStamps = 8;
+__device__ unsigned long long* g_trace_buf = nullptr;
+__device__ unsigned int g_trace_seq = 0;
+extern "C" int mi_debug_trace(void* buf) {
+  unsigned int zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_seq), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return 0;
+}
+#define MI_TRACE_BEGIN()                                                                            \
+  unsigned long long* tb_ = nullptr;                                                                \
+  if (g_trace_buf && blockIdx.x < kTraceBlocks)                                                     \
+    tb_ = g_trace_buf + ((size_t)(__hip_atomic_load(&g_trace_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % kTraceLaunches) * kTraceBlocks + blockIdx.x) * kTraceStamps;
+#define MI_STAMP(k) do { if (tb_ && threadIdx.x == 0) tb_[k] = wall_clock64(); } while (0)
+#define MI_TRACE_END() do { if (tb_ && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_trace_seq, 1u); } while (0)
+#else
+#define MI_TRACE_BEGIN()
+#define MI_STAMP(k)
+#define MI_TRACE_END()
+#endif
+
 // Work decomposition.  A work-group is 8 waves; KS of them (KS in {1,2,4,8}, chosen on the
 // host from the number of row-tiles) split the K dimension of ONE row-tile, so a work-group
 // covers 8/KS row-tiles at a time.  KS = 1: waves never meet (no barrier, no LDS reduction).
@@ -329,6 +354,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   const int my_units = blockIdx.x < units ? ceil_div(units - blockIdx.x, gridDim.x) : 0;
   const int total = my_units * nb;
   const bool col_ok = c < M;
+  MI_TRACE_BEGIN();
+  MI_STAMP(0);
 
   // Two batches of kGemvU x 1 KiB are in flight per wave (16 KiB); two work-groups of 8 waves
   // per CU keep 256 KiB per CU moving.
@@ -362,6 +389,7 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   __builtin_amdgcn_sched_barrier(0);
   issue(bufA, 0);
   __builtin_amdgcn_sched_barrier(0);
+  MI_STAMP(1);
   if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -373,7 +401,9 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   }
   if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, reinterpret_cast<float*>(red));
   else gemv_stage_late<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
+  MI_STAMP(2);
   __syncthreads();
+  MI_STAMP(3);
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int parity = 0;
@@ -423,9 +453,12 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   for (int i = 0; i < total; i += 2) {
     issue(bufB, i + 1);
     process(bufA, i);
+    if (i == 0) MI_STAMP(4);
     issue(bufA, i + 2);
     if (i + 1 < total) process(bufB, i + 1);
   }
+  MI_STAMP(5);
+  MI_TRACE_END();
 }
 
 static int gemv_pick_ks(int NT, int KT, int slots) {
