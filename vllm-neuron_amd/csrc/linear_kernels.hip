@@ -106,6 +106,76 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, int m, int n0, 
   }
 }
 
+// Operands the epilogue needs from memory besides the accumulator (the residual it adds to; the
+// rotary factors and the KV slot of the token).  The GEMV requests them for the work-group's
+// first row-tile in its prologue, so that the end of the kernel is not a chain of dependent
+// L2 round trips (position -> cos/sin -> store) behind the last weight batch.
+template <int EPI> struct EpiPre {};
+template <> struct EpiPre<EPI_RESID> { float4 r; };
+template <> struct EpiPre<EPI_QKV> { float2 cs, sn; int pos, slot; };
+
+// independent loads (requested with the kernel's first operands) ...
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch(const EpiArgs& e, int m, int n0, EpiPre<EPI>& p) {
+  if constexpr (EPI == EPI_RESID) {
+    p.r = *reinterpret_cast<const float4*>(e.resid_in + (size_t)m * e.ld_out + n0);
+  } else if constexpr (EPI == EPI_QKV) {
+    p.pos = e.pos[m];
+    p.slot = e.slots[m];
+  }
+}
+// ... and the ones that hang off them (requested once the activations are staged: the position
+// has long arrived, and nothing waits for these before the last weight batch)
+template <int EPI>
+__device__ __forceinline__ void epi_prefetch_dependent(const EpiArgs& e, int n0, EpiPre<EPI>& p) {
+  if constexpr (EPI == EPI_QKV) {
+    const int qk_end = e.q_dim + e.kv_dim;
+    const int nn = n0 < qk_end ? n0 : 0;                      // V columns: any valid table entry
+    const int j = (nn < e.q_dim ? nn : nn - e.q_dim) % e.hd;
+    const size_t at = (size_t)p.pos * (e.hd >> 1) + (j >> 1);
+    p.cs = *reinterpret_cast<const float2*>(e.rope_cos + at);
+    p.sn = *reinterpret_cast<const float2*>(e.rope_sin + at);
+  }
+}
+
+// epilogue_lds with the prefetched operands
+template <int EPI>
+__device__ __forceinline__ void epilogue_pre(const EpiArgs& e, int m, int n0, const float* sc4, const float* b4,
+                                             f32x4_t v, const EpiPre<EPI>& p) {
+  if constexpr (EPI == EPI_RESID || EPI == EPI_QKV) {
+    const float4 sc = *reinterpret_cast<const float4*>(sc4);
+    v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+    if (b4) {
+      const float4 b = *reinterpret_cast<const float4*>(b4);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI == EPI_RESID) {
+      *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ld_out + n0) =
+          make_float4(p.r.x + v[0], p.r.y + v[1], p.r.z + v[2], p.r.w + v[3]);
+    } else {
+      const int qk_end = e.q_dim + e.kv_dim;
+      if (n0 < qk_end) {
+        const float a0 = v[0] * p.cs.x - v[1] * p.sn.x, a1 = v[1] * p.cs.x + v[0] * p.sn.x;
+        const float b0 = v[2] * p.cs.y - v[3] * p.sn.y, b1 = v[3] * p.cs.y + v[2] * p.sn.y;
+        v[0] = a0; v[1] = a1; v[2] = b0; v[3] = b1;
+      }
+      const uint2 packed = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      if (n0 < e.q_dim) {
+        *reinterpret_cast<uint2*>(e.q_out + (size_t)m * e.q_dim + n0) = packed;
+      } else if (p.slot >= 0) {
+        const bool is_k = n0 < qk_end;
+        const int rel = is_k ? n0 - e.q_dim : n0 - qk_end;
+        const int head = rel / e.hd, d = rel % e.hd;
+        const int blk = p.slot / e.block_size, off = p.slot % e.block_size;
+        uint16_t* pool = is_k ? e.kpool : e.vpool;
+        *reinterpret_cast<uint2*>(pool + (((size_t)blk * e.nkv + head) * e.block_size + off) * e.hd + d) = packed;
+      }
+    }
+  } else {
+    epilogue_lds<EPI>(e, m, n0, sc4, b4, v);
+  }
+}
+
 // =====================================================================================
 // GEMV (token generation)
 // =====================================================================================
@@ -326,59 +396,62 @@ extern "C" int mi_debug_trace(void* buf) {
 #define MI_TRACE_END()
 #endif
 
-// Work decomposition.  A work-group is 8 waves; KS of them (KS in {1,2,4,8}, chosen on the
-// host from the number of row-tiles) split the K dimension of ONE row-tile, so a work-group
-// covers 8/KS row-tiles at a time.  KS = 1: waves never meet (no barrier, no LDS reduction).
-// The hot loop is branch-free: weight loads are unconditional (addresses clamped into the
-// wave's slice) and out-of-range k-tiles / padding columns read a zeroed LDS slot instead of
-// being predicated off, so hipcc can keep counted vmcnt waits and 2 x U loads in flight.
+// Work decomposition.  A work-group is 8 waves.  KS of them (KS in {1,2,4,8}) split the K
+// dimension of ONE row-tile and a work-group covers TP <= 8/KS row-tiles per pass, both chosen on
+// the host so that every CU streams the same number of bytes (e.g. gate|up of Llama-8B: 1792
+// row-tiles = 256 CUs x 7 -> KS 1, TP 7, the eighth wave only helps staging).  KS = 1: waves never
+// meet (no barrier, no LDS reduction).
+// The hot loop is branch-free: weight loads are unconditional and never predicated (a batch that
+// does not exist is requested as ONE 16-byte line, every lane the same address; k-tiles past the
+// wave's slice re-request its last tile, an L1 hit, and multiply a zeroed LDS slot), so hipcc keeps
+// counted vmcnt waits.  A CU holds at most ~64 wave-loads in flight whatever its waves ask for
+// (measured: ~24 GB/s per CU from HBM), so the queue is kept full rather than deep: batch A before
+// the activations are staged, batch B before the work-group meets, then A/B alternate.
 template <int WD, int PRO, int EPI, int KS>
 __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __restrict__ W, int NT, int KT,
-                                                               int M, int K, ProArgs p, EpiArgs e) {
+                                                               int M, int K, int TP, ProArgs p, EpiArgs e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint4* xf = reinterpret_cast<uint4*>(smem);
   const int zero_slot = (M * K) >> 3;  // one extra 16-byte slot of zeros behind the image
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2 + 16);
   float* sc_lds = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16);
   float* bi_lds = sc_lds + kGemvMaxTilesPerWg * 16;
-  constexpr int TPW = kGemvWaves / KS;  // row-tiles per work-group pass
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   const int tsub = wave / KS, kslice = wave % KS;
+  const bool wave_on = tsub < TP;      // waves beyond KS * TP stage activations and wait
   const int ktw = ceil_div(KT, KS);
   const int kbeg = min(kslice * ktw, KT), kend = min(kbeg + ktw, KT);
   const int klast = max(kend - 1, 0);
   const int nb = ceil_div(ktw, kGemvU);  // batches per row-tile, same for every wave
-  const int units = ceil_div(NT, TPW);
+  const int units = ceil_div(NT, TP);
   const int my_units = blockIdx.x < units ? ceil_div(units - blockIdx.x, gridDim.x) : 0;
   const int total = my_units * nb;
   const bool col_ok = c < M;
   MI_TRACE_BEGIN();
   MI_STAMP(0);
 
-  // Two batches of kGemvU x 1 KiB are in flight per wave (16 KiB); two work-groups of 8 waves
-  // per CU keep 256 KiB per CU moving.
   u32x4_t bufA[kGemvU], bufB[kGemvU];
-  // Two-buffer software pipeline; issue() is unconditional (index clamped: past the end the
-  // last batch is simply requested again, an L2 hit) so the loop body is branch-free.
   auto issue = [&](u32x4_t (&buf)[kGemvU], int i) {
+    const bool live = wave_on && i < total;
     i = min(i, total - 1);
-    const int tile = min((int)(blockIdx.x + (i / nb) * gridDim.x) * TPW + tsub, NT - 1);
+    const int tile = min((int)(blockIdx.x + (i / nb) * gridDim.x) * TP + tsub, NT - 1);
     const int kt0 = kbeg + (i % nb) * kGemvU;
-    const uint4* base = W + (size_t)tile * KT * 64 + lane;
+    const uint4* base = live ? W + (size_t)tile * KT * 64 + lane : W;
+    const size_t kstep = live ? 64 : 0;
 #pragma unroll
-    for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * 64);
+    for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * kstep);
   };
 
   // ---- prologue: own operands first, then the first weight batch, then consume (see above) ---
-  const int nsc = my_units * TPW * 16;   // scale / bias of local tile slot j = pass * TPW + sub-tile
+  const int nsc = my_units * TP * 16;   // scale / bias of local tile slot j = pass * TP + sub-tile
   float scv[2], biv[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int j = min(tid + q * (int)blockDim.x, nsc - 1);
     const int slot = j >> 4, r = j & 15;
-    const int tile = min((int)(blockIdx.x + (slot / TPW) * gridDim.x) * TPW + (slot % TPW), NT - 1);
+    const int tile = min((int)(blockIdx.x + (slot / TP) * gridDim.x) * TP + (slot % TP), NT - 1);
     scv[q] = e.scale[tile * 16 + r];
     biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
   }
@@ -386,6 +459,10 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   float pro_h[ProShape<PRO>::NH][8], pro_p[ProShape<PRO>::NP][8], pro_g[8];
   const bool early = gemv_pro_is_early<PRO>(M, K);
   gemv_pro_load<PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g);   // unconditional (clamped); ignored on the late path
+  // epilogue operands of this work-group's first row-tile (clamped; used by the finishing lanes)
+  const int tile0 = min((int)blockIdx.x * TP + min(tsub, TP - 1), NT - 1);
+  EpiPre<EPI> epre;
+  epi_prefetch<EPI>(e, min(c, M - 1), tile0 * 16 + g * 4, epre);
   __builtin_amdgcn_sched_barrier(0);
   issue(bufA, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -402,6 +479,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, reinterpret_cast<float*>(red));
   else gemv_stage_late<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
   MI_STAMP(2);
+  epi_prefetch_dependent<EPI>(e, tile0 * 16 + g * 4, epre);
+  issue(bufB, 1);   // a full queue only blocks a wave that would wait at the barrier anyway
   __syncthreads();
   MI_STAMP(3);
 
@@ -420,25 +499,29 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
     }
   };
   auto finish_tile = [&](int i) {
-    const int tile = (int)(blockIdx.x + (i / nb) * gridDim.x) * TPW + tsub;
-    const int lslot = ((i / nb) * TPW + tsub) * 16 + g * 4;
+    const int pass = i / nb;
+    const int tile = (int)(blockIdx.x + pass * gridDim.x) * TP + tsub;
+    const int lslot = (pass * TP + min(tsub, TP - 1)) * 16 + g * 4;
     const float* sc4 = sc_lds + lslot;
     const float* b4 = e.bias ? bi_lds + lslot : nullptr;
-    if constexpr (KS == 1) {
-      if (col_ok && tile < NT) epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, acc);
-    } else {  // combine the K-slices in wave order (deterministic)
+    const bool mine = wave_on && col_ok && tile < NT;
+    f32x4_t s = acc;
+    if constexpr (KS > 1) {  // combine the K-slices in wave order (deterministic)
       red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
       __syncthreads();
       if (kslice == 0) {
-        f32x4_t s = red[(parity * kGemvWaves + wave) * 64 + lane];
+        s = red[(parity * kGemvWaves + wave) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < KS; ++w) {
           const f32x4_t t = red[(parity * kGemvWaves + wave + w) * 64 + lane];
           s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
-        if (col_ok && tile < NT) epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s);
       }
       parity ^= 1;
+    }
+    if (kslice == 0 && mine) {
+      if (pass == 0) epilogue_pre<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s, epre);
+      else epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s);
     }
     acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };
@@ -451,52 +534,57 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   };
 
   for (int i = 0; i < total; i += 2) {
-    issue(bufB, i + 1);
     process(bufA, i);
     if (i == 0) MI_STAMP(4);
     issue(bufA, i + 2);
     if (i + 1 < total) process(bufB, i + 1);
+    issue(bufB, i + 3);
   }
   MI_STAMP(5);
   MI_TRACE_END();
 }
 
-static int gemv_pick_ks(int NT, int KT, int slots) {
-  // `slots` work-groups are resident at once.  Prefer the K-split that (1) needs the fewest
-  // passes of work-groups over the chip, then (2) fills the most slots, then (3) splits K
-  // least (KS = 1 needs no barrier at all).
-  int best = 8, best_pass = 1 << 30, best_busy = 0;
+// (KS, TP) for NT row-tiles of KT k-tiles on `slots` resident work-groups: fewest k-tiles on the
+// busiest CU (passes x TP x KT/KS x KS), then the fewest passes, then the most streaming waves,
+// then the smallest K split.
+struct GemvShape { int ks, tp; };
+static GemvShape gemv_pick_shape(int NT, int KT, int slots) {
+  GemvShape best{8, 1};
+  long best_load = 1L << 60;
+  int best_pass = 1 << 30, best_waves = 0;
   for (int ks = 1; ks <= 8; ks *= 2) {
     if (KT < ks) break;
-    const int units = ceil_div(NT, kGemvWaves / ks);
-    const int passes = ceil_div(units, slots), busy = units < slots ? units : slots;
-    if (passes < best_pass || (passes == best_pass && busy > best_busy)) {
-      best = ks; best_pass = passes; best_busy = busy;
+    for (int tp = 1; tp * ks <= kGemvWaves; ++tp) {
+      const int units = ceil_div(NT, tp);
+      const int passes = ceil_div(units, slots);
+      const long load = (long)passes * tp * ceil_div(KT, ks) * ks;
+      const int waves = tp * ks;
+      const bool better = load < best_load || (load == best_load && (passes < best_pass ||
+                          (passes == best_pass && (waves > best_waves))));
+      if (better) { best = {ks, tp}; best_load = load; best_pass = passes; best_waves = waves; }
     }
   }
   return best;
 }
 
 template <int WD, int PRO, int EPI, int KS>
-static int launch_gemv_ks(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s, int num_cu) {
+static int launch_gemv_ks(const LinearW& w, int M, int TP, const ProArgs& p, const EpiArgs& e, hipStream_t s, int num_cu) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
   const size_t lds = gemv_lds_bytes(M, w.K);
   auto kern = gemv_kernel<WD, PRO, EPI, KS>;
   static bool attr_set = false;  // per instantiation
-  static int wg_per_cu = 1;
   if (!attr_set) {
     MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  // the grid is one resident wave of work-groups, each walking its share of the row-tiles
-  MI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, kern, kGemvWaves * 64, lds));
-  wg_per_cu = wg_per_cu < 1 ? 1 : (wg_per_cu > 2 ? 2 : wg_per_cu);
-  const int units = ceil_div(NT, kGemvWaves / KS);
-  int grid = min(units, num_cu * wg_per_cu);
+  // the grid is one resident wave of work-groups (one per CU: ~200 VGPRs x 8 waves), each walking
+  // its share of the row-tiles
+  const int units = ceil_div(NT, TP);
+  int grid = min(units, num_cu);
   // a work-group caches the scales of at most kGemvMaxTilesPerWg row-tiles
-  grid = max(grid, ceil_div(units * (kGemvWaves / KS), kGemvMaxTilesPerWg));
+  grid = max(grid, ceil_div(units * TP, kGemvMaxTilesPerWg));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s,
-                     reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K, p, e);
+                     reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K, TP, p, e);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -509,11 +597,12 @@ static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArg
     MI_HIP(hipGetDevice(&dev));
     MI_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  switch (gemv_pick_ks(w.N / 16, w.K / tile_k(WD), num_cu * 2)) {
-    case 1: return launch_gemv_ks<WD, PRO, EPI, 1>(w, M, p, e, s, num_cu);
-    case 2: return launch_gemv_ks<WD, PRO, EPI, 2>(w, M, p, e, s, num_cu);
-    case 4: return launch_gemv_ks<WD, PRO, EPI, 4>(w, M, p, e, s, num_cu);
-    default: return launch_gemv_ks<WD, PRO, EPI, 8>(w, M, p, e, s, num_cu);
+  const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
+  switch (sh.ks) {
+    case 1: return launch_gemv_ks<WD, PRO, EPI, 1>(w, M, sh.tp, p, e, s, num_cu);
+    case 2: return launch_gemv_ks<WD, PRO, EPI, 2>(w, M, sh.tp, p, e, s, num_cu);
+    case 4: return launch_gemv_ks<WD, PRO, EPI, 4>(w, M, sh.tp, p, e, s, num_cu);
+    default: return launch_gemv_ks<WD, PRO, EPI, 8>(w, M, sh.tp, p, e, s, num_cu);
   }
 }
 
