@@ -233,12 +233,20 @@ __device__ __forceinline__ void gemv_pro_load(const ProArgs& p, int M, int K, u3
                                               float (&g)[8]) {
   const int tid = threadIdx.x, nthr = blockDim.x, nchunk = K >> 3;
   if constexpr (PRO == PRO_BF16) {
+    // As many 16-byte chunks per thread as the image needs, in groups of 4 (work-group-uniform
+    // branches; inside a group the index is clamped, never predicated).  Loads nobody needs would
+    // still take slots of the CU's ~64-deep load queue ahead of the first weight batch.
     const int total = M * nchunk;
 #pragma unroll
-    for (int q = 0; q < kXMax; ++q) {
-      const int ic = min(tid + q * nthr, total - 1);   // clamped, never predicated
-      const int m = ic / nchunk, c8 = ic - m * nchunk;
-      xv[q] = *reinterpret_cast<const u32x4_t*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+    for (int q0 = 0; q0 < kXMax; q0 += 4) {
+      if (q0 * nthr < total) {
+#pragma unroll
+        for (int q = q0; q < q0 + 4; ++q) {
+          const int ic = min(tid + q * nthr, total - 1);
+          const int m = ic / nchunk, c8 = ic - m * nchunk;
+          xv[q] = *reinterpret_cast<const u32x4_t*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
+        }
+      }
     }
   } else {
     const int c0 = min(tid, nchunk - 1);
