@@ -144,6 +144,17 @@ int mi_profile_read(mi_ctx* ctx, int32_t* launches /*[MI_K_NUM]*/, float* ms /*[
 int mi_tp_unique_id(void* out128);
 int mi_tp_init(mi_ctx* ctx, const void* id128);
 
+/* The same, with the two collectives supplied by the caller instead of RCCL (a custom xGMI
+ * transport; the single-GPU loopback that tests/test_tp_loopback_gpu.py uses to run every
+ * rank's shard on one device).  all_reduce: in-place fp32 sum of buf[count] over the ranks;
+ * all_gather: recv[rank * count .. ] = rank's send[count].  Both are called from mi_forward on
+ * the calling thread, must be ordered after the work already queued on `stream` and must leave
+ * their result visible to work queued on it afterwards; return 0 on success.  Decode steps are
+ * launched eagerly (no graph capture) on a context with collectives. */
+typedef int (*mi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
+typedef int (*mi_allgather_fn)(void* user, const void* send, void* recv, size_t count, void* stream);
+int mi_tp_init_transport(mi_ctx* ctx, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user);
+
 /* ---- per-kernel entry points (device pointers; stream may be NULL) -------------------- */
 
 /* Quantize + re-tile a row-major fp32 [N, K] device matrix.  scale_out [N] fp32.

@@ -182,6 +182,18 @@ class NativeModel:
         assert len(uid) == 128
         check(self.lib.mi_tp_init(self._ctx, C.create_string_buffer(uid, 128)))
 
+    def tp_init_transport(self, all_reduce, all_gather) -> None:
+        """Collectives supplied by the caller instead of RCCL (include/mi355x_vllm.h:
+        mi_tp_init_transport).  all_reduce(buf_ptr, count, stream_ptr) -> 0 / nonzero,
+        all_gather(send_ptr, recv_ptr, count, stream_ptr) -> 0 / nonzero."""
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        self._xport = (AR(lambda user, buf, n, st: int(all_reduce(buf, n, st))),
+                       AG(lambda user, snd, rcv, n, st: int(all_gather(snd, rcv, n, st))))   # keep alive
+        self.lib.mi_tp_init_transport.argtypes = [C.c_void_p, AR, AG, C.c_void_p]
+        self.lib.mi_tp_init_transport.restype = C.c_int
+        check(self.lib.mi_tp_init_transport(self._ctx, self._xport[0], self._xport[1], None))
+
     def set_num_blocks(self, num_blocks: int) -> None:
         check(self.lib.mi_set_num_blocks(self._ctx, num_blocks))
         self.cfg.num_blocks = num_blocks

@@ -109,6 +109,11 @@ struct mi_ctx {
   int last_B = 0, last_MB = 0;           // shape of the last token-generation call (mi_replay_decode)
   Prof prof;
   ncclComm_t comm = nullptr;
+  // caller-supplied collectives in place of RCCL (mi_tp_init_transport)
+  mi_allreduce_fn xport_allreduce = nullptr;
+  mi_allgather_fn xport_allgather = nullptr;
+  void* xport_user = nullptr;
+  bool collective() const { return comm != nullptr || xport_allreduce != nullptr; }
 };
 
 namespace {
@@ -205,8 +210,15 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
 }
 
 int all_reduce_partial(mi_ctx* c, int rows) {
-  if (!c->comm) return MI_OK;
+  if (!c->collective()) return MI_OK;
   Scope sc(c, MI_K_COMM);
+  if (c->xport_allreduce) {
+    if (c->xport_allreduce(c->xport_user, c->partial, (size_t)rows * c->H, c->stream) != 0) {
+      set_error("all-reduce transport callback failed");
+      return MI_ECOMM;
+    }
+    return MI_OK;
+  }
   ncclResult_t r = ncclAllReduce(c->partial, c->partial, (size_t)rows * c->H, ncclFloat, ncclSum, c->comm, c->stream);
   if (r != ncclSuccess) {
     set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
@@ -255,7 +267,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
                                  c->nkv_l, c->hd, c->attn_out, s));
     }
-    const bool tp = c->comm != nullptr;  // a communicator (even of one rank) selects the collective path
+    const bool tp = c->collective();  // a communicator (even of one rank) selects the collective path
     {  // O projection.  TP = 1: straight into the residual stream (resid' = resid + y);
        // TP > 1: fp32 partial -> RCCL all-reduce -> folded in by the next norm prologue.
       ProArgs p{};
@@ -310,7 +322,13 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     e.out_f32 = c->logits; e.ld_out = c->V_l;
     MI_TRY(run_linear(c, c->lm_head, logits_rows, PRO_NORM, p, EPI_F32, e));
   }
-  if (c->comm) {
+  if (c->xport_allgather) {
+    Scope sc(c, MI_K_COMM);
+    if (c->xport_allgather(c->xport_user, c->logits, c->logits_all, (size_t)k.max_num_seqs * c->V_l, s) != 0) {
+      set_error("all-gather transport callback failed");
+      return MI_ECOMM;
+    }
+  } else if (c->comm) {
     Scope sc(c, MI_K_COMM);
     ncclResult_t r = ncclAllGather(c->logits, c->logits_all, (size_t)k.max_num_seqs * c->V_l, ncclFloat, c->comm, s);
     if (r != ncclSuccess) {
@@ -324,7 +342,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
 int fetch_logits(mi_ctx* c, int nrows, float* out) {
   const mi_model_config& k = c->cfg;
   const int V = k.vocab_size;
-  if (!c->comm) {
+  if (!c->collective()) {
     MI_HIP(hipMemcpyAsync(c->h_logits, c->logits, (size_t)nrows * V * 4, hipMemcpyDeviceToHost, c->stream));
     MI_HIP(hipStreamSynchronize(c->stream));
     memcpy(out, c->h_logits, (size_t)nrows * V * 4);
@@ -472,7 +490,8 @@ float bf16_bits_to_f32(uint16_t h) {
 
 int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
   const int key = B * 65536 + MB;
-  if (!c->cfg.use_graphs || c->prof.on) return run_layers(c, B, true, B, MB, 0, B, 0);
+  // a caller-supplied transport runs on the host thread: never captured
+  if (!c->cfg.use_graphs || c->prof.on || c->xport_allreduce) return run_layers(c, B, true, B, MB, 0, B, 0);
   auto it = c->graphs.find(key);
   if (it == c->graphs.end()) {
     // one eager pass first: sets every kernel's attributes outside of capture
@@ -649,7 +668,7 @@ int mi_set_num_blocks(mi_ctx* c, int32_t num_blocks) {
 int mi_finalize(mi_ctx* c) {
   MI_CHECK(c && !c->finalized, "bad state");
   MI_CHECK(c->have_lm_head, "lm_head.weight (or tied embed_tokens) was never loaded");
-  MI_CHECK(c->cfg.tp_degree == 1 || c->comm != nullptr, "tp_degree > 1: call mi_tp_init before mi_finalize");
+  MI_CHECK(c->cfg.tp_degree == 1 || c->collective(), "tp_degree > 1: call mi_tp_init before mi_finalize");
   const mi_model_config& k = c->cfg;
   MI_HIP(hipSetDevice(k.device_id));
   hipStream_t s = c->stream;
@@ -707,7 +726,7 @@ int mi_finalize(mi_ctx* c) {
     MI_TRY(dmalloc(&c->splitk_ws, c->splitk_ws_bytes / 4, ws));
   }
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
-  if (c->comm) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
+  if (c->collective()) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
   MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
   *ws += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
   c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
@@ -878,6 +897,16 @@ int mi_tp_init(mi_ctx* c, const void* id128) {
   memcpy(&id, id128, 128);
   ncclResult_t r = ncclCommInitRank(&c->comm, c->cfg.tp_degree, id, c->cfg.tp_rank);
   if (r != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); return MI_ECOMM; }
+  return MI_OK;
+}
+
+int mi_tp_init_transport(mi_ctx* c, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user) {
+  MI_CHECK(c && all_reduce && all_gather, "null argument");
+  MI_CHECK(!c->collective(), "tensor-parallel transport already set");
+  MI_CHECK(!c->finalized, "mi_tp_init_transport must precede mi_finalize");
+  c->xport_allreduce = all_reduce;
+  c->xport_allgather = all_gather;
+  c->xport_user = user;
   return MI_OK;
 }
 
