@@ -47,6 +47,10 @@ class MiKvStats(C.Structure):
                 ("num_kv_heads_local", C.c_int32), ("head_dim", C.c_int32), ("num_layers", C.c_int32)]
 
 
+# include/mi355x_vllm.h: mi_allreduce_fn / mi_allgather_fn
+MI_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+MI_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
 _SIGS = {
     "mi_last_error": (C.c_char_p, []),
     "mi_version": (C.c_int, []),
@@ -68,6 +72,7 @@ _SIGS = {
                                   C.POINTER(C.c_double)]),
     "mi_tp_unique_id": (C.c_int, [C.c_void_p]),
     "mi_tp_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mi_tp_init_transport": (C.c_int, [C.c_void_p, MI_ALLREDUCE_FN, MI_ALLGATHER_FN, C.c_void_p]),
     "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_op_untile_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -186,12 +191,8 @@ class NativeModel:
         """Collectives supplied by the caller instead of RCCL (include/mi355x_vllm.h:
         mi_tp_init_transport).  all_reduce(buf_ptr, count, stream_ptr) -> 0 / nonzero,
         all_gather(send_ptr, recv_ptr, count, stream_ptr) -> 0 / nonzero."""
-        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
-        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
-        self._xport = (AR(lambda user, buf, n, st: int(all_reduce(buf, n, st))),
-                       AG(lambda user, snd, rcv, n, st: int(all_gather(snd, rcv, n, st))))   # keep alive
-        self.lib.mi_tp_init_transport.argtypes = [C.c_void_p, AR, AG, C.c_void_p]
-        self.lib.mi_tp_init_transport.restype = C.c_int
+        self._xport = (MI_ALLREDUCE_FN(lambda user, buf, n, st: int(all_reduce(buf, n, st))),
+                       MI_ALLGATHER_FN(lambda user, snd, rcv, n, st: int(all_gather(snd, rcv, n, st))))  # keep alive
         check(self.lib.mi_tp_init_transport(self._ctx, self._xport[0], self._xport[1], None))
 
     def set_num_blocks(self, num_blocks: int) -> None:
