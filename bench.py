@@ -140,8 +140,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # host-side control plane only (unique-id broadcast, barriers, max-over-ranks of the wall
+        # clock): gloo.  The data-path collectives are RCCL calls inside the library, on its own
+        # communicator and stream; a second (torch) RCCL communicator per process would add nothing.
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     def barrier_sync():
         if world > 1:
@@ -219,9 +221,18 @@ def main():
     gemv_ms, gemv_n = prof["ms"]["gemv"], prof["launches"]["gemv"]
     achieved = prof["gemv_weight_bytes"] / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
     step_bytes = weight_bytes_per_step(LLAMA31_8B, world) + kv_bytes_per_step(LLAMA31_8B, world, MAX_NUM_SEQS, DECODE_CTX)
+    # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
+    # gfx950-corrected; tests/pmc_summary.py) -- counters cannot be read from inside the process
+    traffic, traffic_src = None, None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")
+    if world == 1 and args.weight_dtype == "f8e4m3" and os.path.exists(tf):
+        with open(tf) as fh:
+            traffic = json.load(fh)["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)"
     roofline = {"bound": "hbm", "kernel": "mi::gemv_kernel (all projections + lm_head of a step)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(prof["gemv_weight_bytes"] / max(gemv_n, 1)),
                 "launches_per_step": gemv_n // 4, "avg_launch_us": round(gemv_ms * 1e3 / max(gemv_n, 1), 2),
                 "step_algorithmic_GB": round(step_bytes / 1e9, 3),
                 "step_frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
