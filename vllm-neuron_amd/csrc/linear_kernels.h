@@ -59,12 +59,13 @@ int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, con
 // M > 16 context-encoding path (MFMA-bound).  x is always bf16 [T, K].
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e,
                 hipStream_t s);
-// M > 16 with FP8 activations: x8 [T, K] e4m3 (per-token scale in EpiArgs::row_scale), FP8 weights,
+// M > 16 with FP8 activations: x8 = K-step-major e4m3 image [K / 128][ldx >= T rows][128 B] as
+// launch_rowquant_fp8 writes it (per-token scale in EpiArgs::row_scale), FP8 weights,
 // MX-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate.
 int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e,
                    hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
 bool gemm_a8_supported(const LinearW& w);
-// bf16 rows -> e4m3 rows + per-row scale (amax / 448; all-zero row -> 1)
+// bf16 rows -> K-step-major e4m3 image [K / 128][T][128 B] + per-row scale (amax / 448; all-zero row -> 1)
 int launch_rowquant_fp8(const uint16_t* x, int T, int K, int ldx, uint8_t* x8, float* row_scale, hipStream_t s);
 size_t gemv_lds_bytes(int M, int K);
 bool gemv_fits(int M, int K);

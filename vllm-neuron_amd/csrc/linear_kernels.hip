@@ -796,39 +796,49 @@ constexpr int kA8Pitch = kA8BK + 16;   // LDS row pitch in bytes (+16: rows star
 // SPLIT: grid.z K-slices each write their raw fp32 accumulators to slab[z][m][n]; splitk_reduce
 // sums the slabs in slice order (deterministic) and applies the epilogue.  Used when a short
 // prompt leaves the (m-tile x n-tile) grid too small to pull the weights at HBM rate.
-template <int EPI, bool SPLIT>
+template <int EPI, bool SPLIT, int NTW>   // NTW 16-row weight tiles per wave: the tile is (64 NTW) x 128
 __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
                                                       const uint8_t* __restrict__ x8, int ldx, EpiArgs e,
                                                       float* __restrict__ slab) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[kA8BM * kA8Pitch];   // 18 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int m0 = blockIdx.x * kA8BM, nt0 = blockIdx.y * (kA8BN / 16) + wave * 4;
+  // XCD-aware tile order.  Work-groups go round-robin over the 8 XCDs (own 4 MiB L2 each), so
+  // linear id L runs on XCD L % 8.  An XCD takes every eighth 256-row weight slab and walks ALL
+  // token blocks of a slab back to back: the slab (and the K-step the co-resident work-groups
+  // are at) is fetched over the fabric once per XCD instead of once per XCD per token block.
+  constexpr int BN = 64 * NTW;
+  const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(NT, BN / 16);
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
+  if (nblk >= ntiles) return;
+  const int m0 = mblk * kA8BM, nt0 = nblk * (BN / 16) + wave * NTW;
   const int nks_all = K / kA8BK;
   const int ks_per = SPLIT ? ceil_div(nks_all, (int)gridDim.z) : nks_all;
   const int ks_beg = SPLIT ? (int)blockIdx.z * ks_per : 0;
   const int nks = min(ks_beg + ks_per, nks_all);   // exclusive end of this slice
   constexpr int kUnit = 0x7f7f7f7f;   // E8M0 block scales: 2^0
 
-  f32x4_t acc[4][8];
+  f32x4_t acc[NTW][8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // x staging: 128 rows x 128 B per K-step = 1024 chunks of 16 B, 4 per thread
-  u32x4_t xr[4], wr[4][2], wn[4][2];
+  // x staging: 128 rows x 128 B per K-step = 1024 chunks of 16 B, 4 per thread.  The fp8 image
+  // is K-step-major, [K / 128][ldx = T rows][128 B]: a work-group's K-step is 16 KiB contiguous.
+  u32x4_t xr[4], wr[NTW][2], wn[NTW][2];
   auto load_x = [&](int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
       const int m = min(m0 + row, T - 1);   // rows past T are computed on a copy of the last row, never stored
-      xr[i] = *reinterpret_cast<const u32x4_t*>(x8 + (size_t)m * ldx + ks * kA8BK + ch * 16);
+      xr[i] = *reinterpret_cast<const u32x4_t*>(x8 + ((size_t)ks * ldx + m) * kA8BK + ch * 16);
     }
   };
-  auto load_w = [&](u32x4_t (&dst)[4][2], int ks) {
+  auto load_w = [&](u32x4_t (&dst)[NTW][2], int ks) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NTW; ++i) {
       const int nt = min(nt0 + i, NT - 1);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
       const u32x4_t b1 = *reinterpret_cast<const u32x4_t*>(xrow + 64);   // k-tile 2ks+1, chunk g
       const i32x8_t b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NTW; ++i) {
         const i32x8_t a = {(int)wr[i][0][0], (int)wr[i][0][1], (int)wr[i][0][2], (int)wr[i][0][3],
                            (int)wr[i][1][0], (int)wr[i][1][1], (int)wr[i][1][2], (int)wr[i][1][3]};
         acc[i][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i][mt], 0, 0, 0, kUnit, 0, kUnit);
@@ -866,14 +876,14 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
     __syncthreads();
     if (ks + 1 < nks) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NTW; ++i) {
         wr[i][0] = wn[i][0];
         wr[i][1] = wn[i][1];
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NTW; ++i) {
     if (nt0 + i >= NT) continue;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -912,9 +922,12 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
                    float* splitk_ws, size_t splitk_ws_bytes) {
   MI_CHECK(T >= 1, "gemm_a8: T must be >= 1");
   MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
-  MI_CHECK(ldx % 16 == 0 && e.row_scale != nullptr, "gemm_a8: x row stride % 16 and a row scale are required");
+  MI_CHECK(ldx >= T && e.row_scale != nullptr, "gemm_a8: x8 is the K-step-major image of >= T rows, with its row scales");
   const int NT = w.N / 16, KT = w.K / 64, nks = w.K / kA8BK;
-  const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(w.N, kA8BN);
+  // 128 x 128 tiles (three work-groups per CU hide each other's load latency) unless MI_A8_NTW=4
+  static const int ntw = getenv("MI_A8_NTW") ? atoi(getenv("MI_A8_NTW")) : 2;
+  const int bn = 64 * ntw;
+  const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(w.N, bn);
   // K-split only when the tile grid cannot occupy the chip and the slabs stay small
   int KS = 1;
   if (splitk_ws && mtiles * ntiles < 192) {
@@ -922,13 +935,16 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
     while (KS > 1 && (size_t)KS * T * w.N * sizeof(float) > splitk_ws_bytes) --KS;
   }
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
-  dim3 grid(mtiles, ntiles, KS);
+  dim3 grid(8 * mtiles * ceil_div(ntiles, 8), 1, KS);   // see the kernel: XCD-aware tile order
 #define MI_A8(EPI_) \
   do { \
-    if (KS == 1) { \
-      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
+    if (KS == 1 && ntw == 4) { \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, 4>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
+    } else if (KS == 1) { \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, 2>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
     } else { \
-      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
+      if (ntw == 4) hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, 4>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
+      else hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, 2>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
       hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
     } \
   } while (0)
@@ -1024,7 +1040,9 @@ __global__ __launch_bounds__(256) void rowquant_fp8_kernel(const uint16_t* __res
       const float b = fminf(fmaxf(bf16hi_to_f32(w[k]) / scale, -448.f), 448.f);
       o[k >> 1] |= (f32_to_e4m3fn(a) | (f32_to_e4m3fn(b) << 8)) << (16 * (k & 1));
     }
-    *reinterpret_cast<uint2*>(x8 + (size_t)t * K + c8 * 8) = make_uint2(o[0], o[1]);
+    // K-step-major image: [K / 128][T][128 B] (see gemm_a8_kernel: load_x)
+    const int k0 = c8 * 8;
+    *reinterpret_cast<uint2*>(x8 + ((size_t)(k0 >> 7) * gridDim.x + t) * 128 + (k0 & 127)) = make_uint2(o[0], o[1]);
   }
 }
 

@@ -203,7 +203,7 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
     }
     e.row_scale = c->x8_scale;
     Scope sc(c, MI_K_GEMM);
-    return launch_gemm_a8(L.view(), rows, c->x8, L.K, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
+    return launch_gemm_a8(L.view(), rows, c->x8, rows, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
   }
   Scope sc(c, MI_K_GEMM);
   return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
@@ -956,7 +956,7 @@ int mi_op_qlinear_a8(const void* x, int32_t M, const void* w_tiled, const float*
   if (rc == MI_OK) {
     EpiArgs e{};
     e.scale = scale; e.bias = bias; e.out_f32 = y; e.ld_out = N; e.row_scale = xs;
-    rc = launch_gemm_a8(W, M, x8, K, EPI_F32, e, s);
+    rc = launch_gemm_a8(W, M, x8, M, EPI_F32, e, s);
   }
   hipStreamSynchronize(s);
   hipFree(x8);
