@@ -924,27 +924,31 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
   MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
   MI_CHECK(ldx >= T && e.row_scale != nullptr, "gemm_a8: x8 is the K-step-major image of >= T rows, with its row scales");
   const int NT = w.N / 16, KT = w.K / 64, nks = w.K / kA8BK;
-  // 128 x 128 tiles (three work-groups per CU hide each other's load latency) unless MI_A8_NTW=4
-  static const int ntw = getenv("MI_A8_NTW") ? atoi(getenv("MI_A8_NTW")) : 2;
+  // 128 x 128 tiles: 64 accumulator registers per lane leave room for three work-groups per CU,
+  // which hide each other's load latency (the 256 x 128 tile ran one work-group per CU at 24 % of
+  // the matrix-core rate: 29.7 ms for the 2048 bucket against 22.5 ms; forcing a fourth wave per
+  // SIMD spills inside the K loop: 122 ms)
+  constexpr int ntw = 2;
   const int bn = 64 * ntw;
   const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(w.N, bn);
   // K-split only when the tile grid cannot occupy the chip and the slabs stay small
   int KS = 1;
-  if (splitk_ws && mtiles * ntiles < 192) {
-    KS = min(min(8, nks), ceil_div(256, mtiles * ntiles));
+  // (768 work-groups are resident at once.  Measured on the Llama-8B shapes: below 256 tiles aim
+  // for 512 work-groups, below 384 for 768; splitting larger grids costs more in slab traffic
+  // than it wins -- 6.2 / 8.8 / 13.5 ms for the 256 / 512 / 1024 buckets.)
+  const int tiles = mtiles * ntiles;
+  if (splitk_ws && tiles < 384) {
+    KS = min(min(8, nks), ceil_div(tiles < 256 ? 512 : 768, tiles));
     while (KS > 1 && (size_t)KS * T * w.N * sizeof(float) > splitk_ws_bytes) --KS;
   }
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
   dim3 grid(8 * mtiles * ceil_div(ntiles, 8), 1, KS);   // see the kernel: XCD-aware tile order
 #define MI_A8(EPI_) \
   do { \
-    if (KS == 1 && ntw == 4) { \
-      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, 4>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
-    } else if (KS == 1) { \
-      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, 2>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
+    if (KS == 1) { \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, ntw>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
     } else { \
-      if (ntw == 4) hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, 4>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
-      else hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, 2>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
+      hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, ntw>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
       hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
     } \
   } while (0)
