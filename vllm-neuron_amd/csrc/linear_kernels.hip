@@ -990,38 +990,38 @@ __global__ void allmax_kernel(const float* __restrict__ rowmax, int n, float* __
   if (threadIdx.x == 0) *out = sm[0];
 }
 
-// fp32 -> OCP e4m3fn, round-nearest-even, |f| <= 448 (software: bit-exact by construction)
-__device__ __forceinline__ uint32_t f32_to_e4m3fn(float f) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, f);
-  const uint32_t sign = (u >> 24) & 0x80u;
-  const float a = fabsf(f);
-  uint32_t code;
-  if (!(a < 448.f)) {
-    code = 0x7Eu;
-  } else if (a < 0.015625f) {            // below the smallest normal 2^-6: step 2^-9
-    code = (uint32_t)rintf(a * 512.f);    // 8 rounds up into the first normal, encoding is continuous
-  } else {
-    const uint32_t ub = u & 0x7fffffffu;
-    const uint32_t r = ub + 0x7FFFFu + ((ub >> 20) & 1u);
-    code = ((((r >> 23) - 127u + 7u) << 3) | ((r >> 20) & 7u));
-    code = code > 0x7Eu ? 0x7Eu : code;
-  }
-  return sign | code;
-}
-
 // bf16 activations -> e4m3 + per-token scale: s = amax / 448 (all-zero row: 1), q = rne(x / s).
 // One work-group per row.
+// The row stays in registers between the amax pass and the quantize pass (up to kRqMax 16-byte
+// chunks per thread, K <= 16384); longer rows are re-read.
+constexpr int kRqMax = 8;
 __global__ __launch_bounds__(256) void rowquant_fp8_kernel(const uint16_t* __restrict__ x, int K, int ldx,
                                                            uint8_t* __restrict__ x8, float* __restrict__ row_scale) {
   __shared__ float red[4];
   const int t = blockIdx.x, tid = threadIdx.x;
   const uint16_t* row = x + (size_t)t * ldx;
+  const int nchunk = K / 8;
+  u32x4_t v[kRqMax];
   float amax = 0.f;
-  for (int c8 = tid; c8 < K / 8; c8 += 256) {
-    const uint4 v = *reinterpret_cast<const uint4*>(row + c8 * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(bf16lo_to_f32(w[k])), fabsf(bf16hi_to_f32(w[k]))));
+  for (int q = 0; q < kRqMax; ++q) {
+    const int c8 = tid + q * 256;
+    v[q] = c8 < nchunk ? *reinterpret_cast<const u32x4_t*>(row + c8 * 8) : u32x4_t{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int q = 0; q < kRqMax; ++q)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = v[q][k];
+      amax = fmaxf(amax, fmaxf(fabsf(bf16lo_to_f32(w)), fabsf(bf16hi_to_f32(w))));
+    }
+  for (int c8 = tid + kRqMax * 256; c8 < nchunk; c8 += 256) {
+    const u32x4_t r = *reinterpret_cast<const u32x4_t*>(row + c8 * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t w = r[k];
+      amax = fmaxf(amax, fmaxf(fabsf(bf16lo_to_f32(w)), fabsf(bf16hi_to_f32(w))));
+    }
   }
   amax = fmaxf(amax, __shfl_xor(amax, 1));
   amax = fmaxf(amax, __shfl_xor(amax, 2));
@@ -1034,20 +1034,25 @@ __global__ __launch_bounds__(256) void rowquant_fp8_kernel(const uint16_t* __res
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const float scale = amax > 0.f ? amax / 448.f : 1.f;
   if (tid == 0) row_scale[t] = scale;
-  for (int c8 = tid; c8 < K / 8; c8 += 256) {
-    const uint4 v = *reinterpret_cast<const uint4*>(row + c8 * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  auto emit = [&](const u32x4_t r, int c8) {
     uint32_t o[2] = {0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float a = fminf(fmaxf(bf16lo_to_f32(w[k]) / scale, -448.f), 448.f);
-      const float b = fminf(fmaxf(bf16hi_to_f32(w[k]) / scale, -448.f), 448.f);
+      const uint32_t w = r[k];
+      const float a = fminf(fmaxf(bf16lo_to_f32(w) / scale, -448.f), 448.f);
+      const float b = fminf(fmaxf(bf16hi_to_f32(w) / scale, -448.f), 448.f);
       o[k >> 1] |= (f32_to_e4m3fn(a) | (f32_to_e4m3fn(b) << 8)) << (16 * (k & 1));
     }
     // K-step-major image: [K / 128][T][128 B] (see gemm_a8_kernel: load_x)
     const int k0 = c8 * 8;
     *reinterpret_cast<uint2*>(x8 + ((size_t)(k0 >> 7) * gridDim.x + t) * 128 + (k0 & 127)) = make_uint2(o[0], o[1]);
+  };
+#pragma unroll
+  for (int q = 0; q < kRqMax; ++q) {
+    const int c8 = tid + q * 256;
+    if (c8 < nchunk) emit(v[q], c8);
   }
+  for (int c8 = tid + kRqMax * 256; c8 < nchunk; c8 += 256) emit(*reinterpret_cast<const u32x4_t*>(row + c8 * 8), c8);
 }
 
 int launch_rowquant_fp8(const uint16_t* x, int T, int K, int ldx, uint8_t* x8, float* row_scale, hipStream_t s) {

@@ -5,6 +5,10 @@ namespace mi {
 int launch_embed(const int32_t* ids, const uint16_t* table, int T, int H, float* resid, hipStream_t s);
 int launch_norm_rows(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
                      int H, float eps, uint16_t* y, hipStream_t s);
+// the same row, emitted as the FP8 GEMM's input: bf16-rounded, then e4m3 with scale amax / 448,
+// K-step-major image [H / 128][T][128 B] + row_scale[T]
+int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
+                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s);
 int launch_f32_to_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s);
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t tensor_id, float std, hipStream_t s);
 int launch_fill_f32(float* out, size_t n, float v, hipStream_t s);

@@ -24,10 +24,15 @@ int launch_embed(const int32_t* ids, const uint16_t* table, int T, int H, float*
 }
 
 // h = resid_in (+ partial) -> resid_out (optional); y = bf16(rmsnorm(h) * gain)   (reference K2)
+// FP8: instead of the bf16 row, emit what rowquant_fp8_kernel would make of it -- the row rounded
+// to bf16, then e4m3 with the per-token scale amax / 448 -- as the K-step-major image
+// [H / 128][T][128 B] the FP8 GEMM reads (same arithmetic, one launch and one bf16 round trip less).
+template <bool FP8>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ resid_in, const float* __restrict__ partial,
                                                         float* __restrict__ resid_out, const float* __restrict__ gain,
-                                                        int H, float eps, uint16_t* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float hrow[];  // H floats + 4
+                                                        int H, float eps, uint16_t* __restrict__ y,
+                                                        uint8_t* __restrict__ x8, float* __restrict__ row_scale) {
+  extern __shared__ __attribute__((aligned(16))) float hrow[];  // H floats + 8
   const int t = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)t * H;
   float ss = 0.f;
@@ -46,17 +51,52 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
   const float rinv = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  float amax = 0.f;
   for (int c4 = tid; c4 < H / 4; c4 += 256) {
     const float4 a = *reinterpret_cast<const float4*>(hrow + c4 * 4);
     const float4 g = *reinterpret_cast<const float4*>(gain + c4 * 4);
-    *reinterpret_cast<uint2*>(y + o + c4 * 4) =
-        make_uint2(pack_bf16x2(a.x * rinv * g.x, a.y * rinv * g.y), pack_bf16x2(a.z * rinv * g.z, a.w * rinv * g.w));
+    const uint2 pk = make_uint2(pack_bf16x2(a.x * rinv * g.x, a.y * rinv * g.y), pack_bf16x2(a.z * rinv * g.z, a.w * rinv * g.w));
+    if constexpr (FP8) {
+      *reinterpret_cast<uint2*>(hrow + c4 * 4) = pk;   // own 16-byte slot: the bf16 values, for pass 3
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo_to_f32(pk.x)), fabsf(bf16hi_to_f32(pk.x))),
+                               fmaxf(fabsf(bf16lo_to_f32(pk.y)), fabsf(bf16hi_to_f32(pk.y)))));
+    } else {
+      *reinterpret_cast<uint2*>(y + o + c4 * 4) = pk;
+    }
+  }
+  if constexpr (FP8) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float scale = amax > 0.f ? amax / 448.f : 1.f;
+    if (tid == 0) row_scale[t] = scale;
+    for (int c4 = tid; c4 < H / 4; c4 += 256) {
+      const uint2 pk = *reinterpret_cast<const uint2*>(hrow + c4 * 4);
+      const float v0 = fminf(fmaxf(bf16lo_to_f32(pk.x) / scale, -448.f), 448.f);
+      const float v1 = fminf(fmaxf(bf16hi_to_f32(pk.x) / scale, -448.f), 448.f);
+      const float v2 = fminf(fmaxf(bf16lo_to_f32(pk.y) / scale, -448.f), 448.f);
+      const float v3 = fminf(fmaxf(bf16hi_to_f32(pk.y) / scale, -448.f), 448.f);
+      const uint32_t q = f32_to_e4m3fn(v0) | (f32_to_e4m3fn(v1) << 8) | (f32_to_e4m3fn(v2) << 16) | (f32_to_e4m3fn(v3) << 24);
+      const int k0 = c4 * 4;
+      *reinterpret_cast<uint32_t*>(x8 + ((size_t)(k0 >> 7) * gridDim.x + t) * 128 + (k0 & 127)) = q;
+    }
   }
 }
 int launch_norm_rows(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
                      int H, float eps, uint16_t* y, hipStream_t s) {
   MI_CHECK(H % 4 == 0 && H <= 32768, "rmsnorm: H % 4 == 0 and H <= 32768 required");
-  hipLaunchKernelGGL(norm_rows_kernel, dim3(T), dim3(256), (H + 4) * sizeof(float), s, resid_in, partial, resid_out, gain, H, eps, y);
+  hipLaunchKernelGGL(norm_rows_kernel<false>, dim3(T), dim3(256), (H + 8) * sizeof(float), s, resid_in, partial, resid_out,
+                     gain, H, eps, y, nullptr, nullptr);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
+                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s) {
+  MI_CHECK(H % 128 == 0 && H <= 32768, "rmsnorm + fp8: H % 128 == 0 and H <= 32768 required");
+  hipLaunchKernelGGL(norm_rows_kernel<true>, dim3(T), dim3(256), (H + 8) * sizeof(float), s, resid_in, partial, resid_out,
+                     gain, H, eps, nullptr, x8, row_scale);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

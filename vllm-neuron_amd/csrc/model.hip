@@ -190,14 +190,19 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   }
   const uint16_t* x = p.x;
   int ldx = p.ldx;
+  const bool a8 = c->cfg.prefill_fp8_activations && gemm_a8_supported(L.view());
   if (pro == PRO_NORM) {
     Scope sc(c, MI_K_OTHER);
-    MI_TRY(launch_norm_rows(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->xn, c->stream));
-    x = c->xn;
-    ldx = L.K;
+    if (a8) {   // norm and per-token quantization in one pass over the row
+      MI_TRY(launch_norm_rows_fp8(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->x8, c->x8_scale, c->stream));
+    } else {
+      MI_TRY(launch_norm_rows(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->xn, c->stream));
+      x = c->xn;
+      ldx = L.K;
+    }
   }
-  if (c->cfg.prefill_fp8_activations && gemm_a8_supported(L.view())) {
-    {
+  if (a8) {
+    if (pro != PRO_NORM) {
       Scope sc(c, MI_K_OTHER);
       MI_TRY(launch_rowquant_fp8(x, rows, L.K, ldx, c->x8, c->x8_scale, c->stream));
     }
