@@ -116,6 +116,20 @@ int mi_forward(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_ids,
                const int64_t* full_context_lens, const int64_t* computed_context_lens,
                float* logits_out);
 
+/* The same call with on-device sampling (the reference's on_device_sampling_config path: the model
+ * returns sampled ids instead of logits, loader.py:352-356, 367-375).  sampling_params: [B, 3] fp32
+ * rows (top_k, top_p, temperature) as the reference packs them (runner.py:1106-1140; greedy
+ * requests arrive as top_k = 1), or NULL for all-greedy.  top_k is capped at 256.  top_k == 1 is
+ * argmax with the lowest index on ties (== torch.argmax on the logits mi_forward would return);
+ * otherwise the id is drawn from the temperature-scaled softmax over the top_k logits cut to the
+ * top_p nucleus, with u = splitmix64(seed, row) -- a pure function of (logits, params, seed, row),
+ * restated in oracle/sampling.py.  tokens_out [B] int64. */
+int mi_forward_tokens(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_ids,
+                      const int64_t* position_ids, const int64_t* seq_ids, const int64_t* block_table,
+                      int32_t MB, const int64_t* slot_mapping, int32_t SM,
+                      const int64_t* full_context_lens, const int64_t* computed_context_lens,
+                      const float* sampling_params, uint64_t seed, int64_t* tokens_out);
+
 /* Replay the LAST token-generation call `steps` times with its inputs left resident in HBM
  * (no host round trip in between) and return the elapsed time measured with HIP events on the
  * context's stream.  For benchmarking the hot path itself: mi_forward adds one small H2D copy
@@ -156,6 +170,12 @@ typedef int (*mi_allgather_fn)(void* user, const void* send, void* recv, size_t 
 int mi_tp_init_transport(mi_ctx* ctx, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user);
 
 /* ---- per-kernel entry points (device pointers; stream may be NULL) -------------------- */
+
+/* The sampler of mi_forward_tokens on caller-supplied logits: logits [B, V] fp32, sampling_params
+ * [B, 3] fp32 (top_k, top_p, temperature) or NULL = greedy, tokens_out [B] int32 -- all device. */
+int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
+                 int32_t* tokens_out, void* stream);
+
 
 /* Quantize + re-tile a row-major fp32 [N, K] device matrix.  scale_out [N] fp32.
  * tiled_out: N*K bytes (fp8/int8) or 2*N*K (bf16), kernel-native 16-row tiles. */

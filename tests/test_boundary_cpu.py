@@ -216,7 +216,7 @@ def test_default_config_fields():                               # :535-588
     assert d["padding_side"] == "right" and d["pa_block_size"] == 32
     assert d["pa_num_blocks"] == (256 // 32) * 4
     assert d["is_block_kv_layout"] is True and d["is_prefix_caching"] is True
-    assert d["on_device_sampling_config"] is None               # CPU sampling is the implemented path
+    assert d["on_device_sampling_config"] is None               # CPU sampling is the default (parity) path
 
 
 @pytest.mark.parametrize("max_model_len,max_num_seqs,block_size,is_block,pa_num_blocks,ok", [

@@ -63,6 +63,32 @@ def test_engine_generate_matches_hf_golden(name, prefix):
     eng.worker.model_runner.model.model.close()
 
 
+@pytest.mark.parametrize("name,prefix", [("llama31_like", True), ("qwen25_like", False)])
+def test_engine_on_device_sampling_matches_hf_golden(name, prefix):
+    """on_device_sampling_config set: the model call returns ids (mi_forward_tokens) and the CPU
+    sampler is never entered; greedy requests must still reproduce the HF goldens."""
+    from vllm_neuron_amd._vllm_compat import SamplingParams
+    from vllm_neuron_amd.engine import MI355XEngine
+    cfg = zoo_config(name)
+    eng = MI355XEngine(hf_like(name), max_model_len=256, max_num_seqs=4, block_size=32,
+                       enable_prefix_caching=prefix,
+                       override_mi355x_config={"state_dict": make_weights(cfg, 1),
+                                               "on_device_sampling_config": {"dynamic": True, "deterministic": False}})
+    runner = eng.worker.model_runner
+
+    def no_cpu_sampler(*a, **k):
+        raise AssertionError("CPU sampler entered although on_device_sampling_config is set")
+    runner._cpu_sample = no_cpu_sampler
+    prompts = make_prompts(cfg.vocab_size, 0)
+    outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12))
+    check_against_golden(name, outs)
+    # random sampling on device: reproducible for a fixed engine seed and call sequence, ids in range
+    sp = SamplingParams(temperature=0.8, top_k=20, top_p=0.9, max_tokens=8)
+    a = [o.token_ids for o in eng.generate(prompts[:2], sp)]
+    assert all(0 <= t < cfg.vocab_size for ids in a for t in ids)
+    runner.model.model.close()
+
+
 def test_engine_quantized_fp8_runs_and_is_deterministic():
     from vllm_neuron_amd._vllm_compat import SamplingParams
     from vllm_neuron_amd.engine import MI355XEngine

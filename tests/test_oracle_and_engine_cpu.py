@@ -288,3 +288,65 @@ def test_tp_plan_two_ranks_gloo():
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_tp_rank_main, args=(2, port, None), nprocs=2, join=True)
+
+
+# ---- on-device sampling rule (oracle/sampling.py) -------------------------------------------------
+def test_sampling_rule_properties():
+    import numpy as np
+    from oracle import sampling as osamp
+    rng = np.random.default_rng(0)
+    logits = (rng.standard_normal(300) * 2).astype(np.float32)
+    logits[[5, 17]] = logits.max() + 1                      # a tie at the top
+    assert osamp.sample_row(logits, 1, 0.5, 0.7, seed=3, row=0) == 5          # greedy: first maximum
+    idx, w = osamp.kept_distribution(logits, 10, 1.0, 1.0)
+    assert idx.tolist()[:2] == [5, 17] and len(idx) == 10 and np.all(np.diff(w) <= 0)
+    # the nucleus shrinks with top_p and always keeps the head
+    sizes = [len(osamp.kept_distribution(logits, 50, p, 1.0)[0]) for p in (1e-6, 0.3, 0.6, 0.9, 1.0)]
+    assert sizes[0] == 1 and sizes == sorted(sizes) and sizes[-1] == 50
+    # top_k is capped at 256 and at the vocabulary
+    assert len(osamp.kept_distribution(logits, 10_000, 1.0, 1.0)[0]) == 256
+    # draws are a pure function of (seed, row), stay inside the nucleus, and cover it
+    seen = set()
+    for seed in range(400):
+        t = osamp.sample_row(logits, 4, 1.0, 2.0, seed, 1)
+        assert t == osamp.sample_row(logits, 4, 1.0, 2.0, seed, 1)
+        seen.add(t)
+    assert seen == set(osamp.kept_distribution(logits, 4, 1.0, 2.0)[0].tolist())
+    u = [float(osamp.uniform(s, r)) for s in range(50) for r in range(4)]
+    assert 0.0 <= min(u) and max(u) < 1.0 and 0.35 < sum(u) / len(u) < 0.65
+
+
+def test_on_device_sampling_config_is_accepted_and_routes_to_tokens():
+    """The adapter returns ids (not logits) when on_device_sampling_config is set, packs the
+    reference's (top_k, top_p, temperature) rows and advances the draw counter per call."""
+    import torch
+    from vllm_neuron_amd.worker import mi355x_model_loader as loader
+
+    class FakeNative:
+        def __init__(self):
+            self.calls = []
+
+        def forward_tokens(self, ids, pos, seq, bt, sm, full, comp, sampling_params=None, seed=0):
+            self.calls.append((sampling_params.clone(), seed))
+            return torch.arange(ids.shape[0], dtype=torch.int64) + 100
+
+        def forward(self, *a, **k):
+            raise AssertionError("logits path taken")
+
+    m = loader.MI355XCausalLM(config=None)
+    m.model = FakeNative()
+    m.mi355x_config = loader.MI355XConfig(is_block_kv_layout=True, on_device_sampling_config={"dynamic": True})
+    m._sample_seed = 7
+    B = 3
+    params = torch.tensor([[1.0, 1.0, 1.0], [20.0, 0.9, 0.8], [256.0, 1.0, 1.0]])
+    kw = dict(input_ids=torch.zeros(B, 1, dtype=torch.long), position_ids=torch.zeros(B, 1, dtype=torch.long),
+              input_block_ids=torch.arange(B), slot_mapping=torch.zeros(B, 1, dtype=torch.long),
+              block_tables=torch.ones(B, 8, dtype=torch.long), full_context_lens=torch.ones(B, 1, dtype=torch.long),
+              computed_context_lens=torch.zeros(B, 1, dtype=torch.long), sampling_params=params)
+    out = m(**kw)
+    out2 = m(**kw)
+    assert out.tolist() == [100, 101, 102] and out2.tolist() == out.tolist()
+    (p1, s1), (p2, s2) = m.model.calls
+    assert torch.equal(p1, params) and s1 == (7 << 32) + 1 and s2 == (7 << 32) + 2
+    so = m.sample(logits=out)
+    assert so.sampled_token_ids.shape == (B, 1)

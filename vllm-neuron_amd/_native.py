@@ -64,6 +64,9 @@ _SIGS = {
     "mi_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p]),
+    "mi_forward_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_uint64, C.c_void_p]),
     "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
     "mi_stream": (C.c_void_p, [C.c_void_p]),
@@ -73,6 +76,7 @@ _SIGS = {
     "mi_tp_unique_id": (C.c_int, [C.c_void_p]),
     "mi_tp_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_tp_init_transport": (C.c_int, [C.c_void_p, MI_ALLREDUCE_FN, MI_ALLGATHER_FN, C.c_void_p]),
+    "mi_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_op_untile_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -217,6 +221,30 @@ class NativeModel:
         check(self.lib.mi_forward(self._ctx, B, S, ids.data_ptr(), pos.data_ptr(), seq.data_ptr(),
                                   bt.data_ptr(), bt.shape[1], sm.data_ptr(), sm.shape[1],
                                   full.data_ptr(), comp.data_ptr(), out.data_ptr()))
+        return out
+
+    def forward_tokens(self, input_ids, position_ids, seq_ids, block_table, slot_mapping,
+                       full_context_lens, computed_context_lens, sampling_params=None, seed: int = 0) -> "torch.Tensor":
+        """The same call with on-device sampling: `sampling_params` [B, 3] fp32 rows
+        (top_k, top_p, temperature) or None for greedy; -> sampled ids [B] int64 (CPU)."""
+        def i64(t):
+            return t.to(torch.int64).contiguous()
+        ids, pos = i64(input_ids), i64(position_ids)
+        B, S = ids.shape
+        bt, sm = i64(block_table).reshape(B, -1), i64(slot_mapping).reshape(B, -1)
+        full, comp = i64(full_context_lens).reshape(-1), i64(computed_context_lens).reshape(-1)
+        seq = i64(seq_ids).reshape(-1) if seq_ids is not None else torch.zeros(B, dtype=torch.int64)
+        sp = None
+        if sampling_params is not None:
+            sp = sampling_params.to(torch.float32).contiguous()
+            if sp.shape != (B, 3):
+                raise ValueError(f"sampling_params must be [B, 3], got {tuple(sp.shape)}")
+        out = torch.empty(B, dtype=torch.int64)
+        check(self.lib.mi_forward_tokens(self._ctx, B, S, ids.data_ptr(), pos.data_ptr(), seq.data_ptr(),
+                                         bt.data_ptr(), bt.shape[1], sm.data_ptr(), sm.shape[1],
+                                         full.data_ptr(), comp.data_ptr(),
+                                         sp.data_ptr() if sp is not None else None, seed & (2 ** 64 - 1),
+                                         out.data_ptr()))
         return out
 
     def replay_decode(self, steps: int) -> float:

@@ -158,7 +158,11 @@ __device__ __forceinline__ void stream_wait(u32x4_t& r) {
 }
 #else
 __device__ __forceinline__ void stream_load16(u32x4_t& dst, const uint4* p) {
+#ifdef MI_STREAM_PLAIN   // probe builds: default cache policy instead of the streaming hint
+  dst = *reinterpret_cast<const u32x4_t*>(p);
+#else
   dst = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#endif
 }
 template <int N>
 __device__ __forceinline__ void stream_wait(u32x4_t&) {}

@@ -12,4 +12,8 @@ int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* res
 int launch_f32_to_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s);
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t tensor_id, float std, hipStream_t s);
 int launch_fill_f32(float* out, size_t n, float v, hipStream_t s);
+// On-device sampling over fp32 logits rows (vocab-parallel segments [T][row_stride][V_l]); params
+// [B,3] = (top_k, top_p, temperature) per row, null = greedy; tokens[B] int32 (device).
+int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int B, const float* params,
+                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s);
 }  // namespace mi

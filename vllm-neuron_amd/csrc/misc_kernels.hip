@@ -141,4 +141,162 @@ int launch_fill_f32(float* out, size_t n, float v, hipStream_t s) {
   return MI_OK;
 }
 
+// =====================================================================================
+// On-device sampling (reference K10: NxDI on-device sampling behind on_device_sampling_config,
+// /root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py:352-356, 367-375; the
+// per-request (top_k, top_p, temperature) rows of runner.py:1106-1140)
+// =====================================================================================
+// One work-group (1024 threads) per sequence over its fp32 logits row.  The row may be split
+// vocab-parallel over T rank segments (TP): element v lives at seg[v / V_l][row][v % V_l].
+//   top_k == 1 : argmax, lowest index on ties (== torch.argmax).
+//   otherwise  : keep the top_k (<= kSampleMaxTopK) logits -- 4-pass radix select on the order-
+//                preserving integer image of the floats, candidates sorted (value desc, index asc)
+//                by a bitonic network in LDS -- p_i = exp((l_i - l_max) / temperature); nucleus:
+//                keep i while the mass BEFORE i is < top_p * total (the first is always kept);
+//                draw u from splitmix64(seed, row) and take the first i whose cumulative mass
+//                exceeds u * kept.  Same arithmetic order as oracle/sampling.py (fp32, serial).
+constexpr int kSampleThreads = 1024;
+constexpr int kSampleMaxTopK = 256;
+constexpr int kSampleCand = 1024;   // candidates kept for the sort (top_k plus ties at the threshold)
+
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
+    const float* __restrict__ logits, int T, int row_stride, int V_l, const float* __restrict__ params /*[B,3] or null*/,
+    unsigned long long seed, int row0, int32_t* __restrict__ tokens) {
+  __shared__ unsigned int hist[256];
+  __shared__ float cand_v[kSampleCand];
+  __shared__ int cand_i[kSampleCand];
+  __shared__ float red_v[kSampleThreads / 64];
+  __shared__ int red_i[kSampleThreads / 64];
+  __shared__ unsigned int s_prefix, s_remaining, s_count;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int V = T * V_l;
+  auto at = [&](int v) -> float { return logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)]; };
+  int top_k = 1;
+  float top_p = 1.f, temperature = 1.f;
+  if (params) {
+    top_k = (int)params[b * 3];
+    top_p = params[b * 3 + 1];
+    temperature = params[b * 3 + 2];
+  }
+  top_k = min(max(top_k, 1), min(kSampleMaxTopK, V));
+
+  if (top_k == 1) {   // ---- greedy ----------------------------------------------------------
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += kSampleThreads) {
+      const float x = at(v);
+      if (x > bv) { bv = x; bi = v; }      // ascending v per thread: strict > keeps the lowest index
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float ov = __shfl_xor(bv, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kSampleThreads / 64; ++w)
+        if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+      tokens[b] = bi == 0x7fffffff ? 0 : bi;   // all-NaN row: token 0
+    }
+    return;
+  }
+
+  // ---- radix select: the key of the top_k-th largest logit --------------------------------
+  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)top_k; }
+  __syncthreads();
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned int prefix = s_prefix;
+    const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int v = tid; v < V; v += kSampleThreads) {
+      const uint32_t key = f32_order_key(at(v));
+      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {      // walk the bins from the top until the remaining rank falls inside one
+      unsigned int rem = s_remaining;
+      int bin = 255;
+      for (; bin > 0; --bin) {
+        if (hist[bin] >= rem) break;
+        rem -= hist[bin];
+      }
+      s_prefix = prefix | ((unsigned)bin << shift);
+      s_remaining = rem;
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;          // key of the top_k-th largest element
+  // ---- candidates: everything >= that key (ties at the threshold included, capped) ---------
+  if (tid == 0) s_count = 0;
+  for (int i = tid; i < kSampleCand; i += kSampleThreads) { cand_v[i] = -INFINITY; cand_i[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int v = tid; v < V; v += kSampleThreads) {
+    const float x = at(v);
+    if (f32_order_key(x) >= kth) {
+      const unsigned int slot = atomicAdd(&s_count, 1u);
+      if (slot < (unsigned)kSampleCand) { cand_v[slot] = x; cand_i[slot] = v; }
+    }
+  }
+  __syncthreads();
+  // bitonic sort of the kSampleCand slots: value descending, index ascending (deterministic)
+  for (int size = 2; size <= kSampleCand; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int i = tid, j = i ^ stride;
+      if (j > i) {
+        const bool desc = (i & size) == 0;
+        const float vi = cand_v[i], vj = cand_v[j];
+        const int ii = cand_i[i], ij = cand_i[j];
+        const bool i_first = vi > vj || (vi == vj && ii < ij);   // i belongs before j in the final order
+        if (desc ? !i_first : i_first) {
+          cand_v[i] = vj; cand_v[j] = vi;
+          cand_i[i] = ij; cand_i[j] = ii;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {        // <= 256 entries: serial fp32 arithmetic in a fixed order
+    const float lmax = cand_v[0];
+    const float inv_t = 1.f / temperature;
+    float total = 0.f;
+    for (int i = 0; i < top_k; ++i) total += expf((cand_v[i] - lmax) * inv_t);
+    const float limit = top_p * total;
+    float kept = 0.f;
+    int nkeep = 0;
+    for (int i = 0; i < top_k; ++i) {
+      if (i > 0 && !(kept < limit)) break;
+      kept += expf((cand_v[i] - lmax) * inv_t);
+      nkeep = i + 1;
+    }
+    const unsigned long long r = splitmix64(seed ^ splitmix64(0x5EEDull + (unsigned long long)(row0 + b)));
+    const float u = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f);   // [0, 1)
+    const float target = u * kept;
+    float cum = 0.f;
+    int pick = nkeep - 1;
+    for (int i = 0; i < nkeep; ++i) {
+      cum += expf((cand_v[i] - lmax) * inv_t);
+      if (cum > target) { pick = i; break; }
+    }
+    tokens[b] = cand_i[pick];
+  }
+}
+
+int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int B, const float* params,
+                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s) {
+  MI_CHECK(B >= 1 && T >= 1 && V_l >= 1, "sample: bad shape");
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(kSampleThreads), 0, s, logits, T, row_stride, V_l, params,
+                     seed, row0, tokens);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 }  // namespace mi

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -102,7 +103,13 @@ struct mi_ctx {
   // step inputs
   int32_t *d_ids = nullptr, *d_pos = nullptr, *d_slots = nullptr, *d_bt = nullptr, *d_ctx = nullptr;
   int32_t *h_ids = nullptr, *h_pos = nullptr, *h_slots = nullptr, *h_bt = nullptr, *h_ctx = nullptr;
+  // the five input arrays above are slices of ONE device block / ONE pinned block: one H2D per call
+  int32_t *d_inputs = nullptr, *h_inputs = nullptr;
+  size_t inputs_elems = 0;
   float* h_logits = nullptr;
+  // on-device sampling: (top_k, top_p, temperature) rows and the sampled ids
+  float *d_sparams = nullptr, *h_sparams = nullptr;
+  int32_t *d_tokens = nullptr, *h_tokens = nullptr;
   int MB_cap = 0;
   size_t weight_bytes = 0, workspace_bytes = 0, kv_bytes = 0;
   std::map<int, hipGraphExec_t> graphs;  // token-generation graph per (B * 65536 + MB)
@@ -597,9 +604,9 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_ids, c->d_pos, c->d_slots, c->d_bt, c->d_ctx, c->x8, c->x8_scale, c->splitk_ws};
+                  c->attn_scratch, c->d_inputs, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws};
   for (void* p : ptrs) hipFree(p);
-  void* hptrs[] = {c->h_ids, c->h_pos, c->h_slots, c->h_bt, c->h_ctx, c->h_logits};
+  void* hptrs[] = {c->h_inputs, c->h_sparams, c->h_tokens, c->h_logits};
   for (void* p : hptrs) if (p) hipHostFree(p);
   hipStreamDestroy(c->stream);
   delete c;
@@ -736,28 +743,66 @@ int mi_finalize(mi_ctx* c) {
   *ws += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
   c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
   const size_t nbt = (size_t)k.max_num_seqs * c->MB_cap;
-  MI_TRY(dmalloc(&c->d_ids, R, ws));
-  MI_TRY(dmalloc(&c->d_pos, R, ws));
-  MI_TRY(dmalloc(&c->d_slots, R, ws));
-  MI_TRY(dmalloc(&c->d_bt, nbt, ws));
-  MI_TRY(dmalloc(&c->d_ctx, (size_t)k.max_num_seqs, ws));
-  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ids), R * 4, hipHostMallocDefault));
-  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pos), R * 4, hipHostMallocDefault));
-  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_slots), R * 4, hipHostMallocDefault));
-  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bt), nbt * 4, hipHostMallocDefault));
-  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctx), (size_t)k.max_num_seqs * 4, hipHostMallocDefault));
+  // inputs: [block tables][context lengths][ids][positions][slots], one block on each side
+  c->inputs_elems = nbt + (size_t)k.max_num_seqs + 3 * R;
+  MI_TRY(dmalloc(&c->d_inputs, c->inputs_elems, ws));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_inputs), c->inputs_elems * 4, hipHostMallocDefault));
+  memset(c->h_inputs, 0, c->inputs_elems * 4);
+  auto carve = [&](int32_t* base) {
+    int32_t* p = base;
+    int32_t* bt = p; p += nbt;
+    int32_t* ctx = p; p += k.max_num_seqs;
+    int32_t* ids = p; p += R;
+    int32_t* pos = p; p += R;
+    int32_t* slots = p;
+    return std::array<int32_t*, 5>{bt, ctx, ids, pos, slots};
+  };
+  {
+    auto d = carve(c->d_inputs), h = carve(c->h_inputs);
+    c->d_bt = d[0]; c->d_ctx = d[1]; c->d_ids = d[2]; c->d_pos = d[3]; c->d_slots = d[4];
+    c->h_bt = h[0]; c->h_ctx = h[1]; c->h_ids = h[2]; c->h_pos = h[3]; c->h_slots = h[4];
+  }
+  MI_TRY(dmalloc(&c->d_sparams, (size_t)k.max_num_seqs * 3, ws));
+  MI_TRY(dmalloc(&c->d_tokens, (size_t)k.max_num_seqs, ws));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_sparams), (size_t)k.max_num_seqs * 3 * 4, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tokens), (size_t)k.max_num_seqs * 4, hipHostMallocDefault));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), (size_t)k.max_num_seqs * k.vocab_size * 4, hipHostMallocDefault));
   MI_HIP(hipStreamSynchronize(s));
   c->finalized = true;
   return MI_OK;
 }
 
-int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const int64_t* position_ids,
-               const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
-               int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
-               float* logits_out) {
+// logits_out != null: the reference's CPU-sampling contract (fp32 logits of the last token of every
+// row to the host).  tokens_out != null: on-device sampling -- the ids are sampled from the device
+// logits and only B integers cross PCIe.
+static int sample_on_device(mi_ctx* c, int nrows, int row0, const float* sampling_params, uint64_t seed,
+                            int64_t* tokens_out) {
+  const mi_model_config& k = c->cfg;
+  hipStream_t s = c->stream;
+  const float* dparams = nullptr;
+  if (sampling_params) {
+    memcpy(c->h_sparams, sampling_params + (size_t)row0 * 3, (size_t)nrows * 3 * 4);
+    MI_HIP(hipMemcpyAsync(c->d_sparams, c->h_sparams, (size_t)nrows * 3 * 4, hipMemcpyHostToDevice, s));
+    dparams = c->d_sparams;
+  }
+  {
+    Scope sc(c, MI_K_OTHER);
+    if (c->collective()) MI_TRY(launch_sample_rows(c->logits_all, k.tp_degree, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s));
+    else MI_TRY(launch_sample_rows(c->logits, 1, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s));
+  }
+  MI_HIP(hipMemcpyAsync(c->h_tokens, c->d_tokens, (size_t)nrows * 4, hipMemcpyDeviceToHost, s));
+  MI_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < nrows; ++i) tokens_out[row0 + i] = c->h_tokens[i];
+  return MI_OK;
+}
+
+static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const int64_t* position_ids,
+                        const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
+                        int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
+                        float* logits_out, const float* sampling_params, uint64_t seed, int64_t* tokens_out) {
   MI_CHECK(c && c->finalized, "mi_forward before mi_finalize");
-  MI_CHECK(input_ids && position_ids && block_table && slot_mapping && full_context_lens && computed_context_lens && logits_out, "null argument");
+  MI_CHECK(input_ids && position_ids && block_table && slot_mapping && full_context_lens && computed_context_lens, "null argument");
+  MI_CHECK((logits_out != nullptr) != (tokens_out != nullptr), "exactly one of logits_out / tokens_out");
   (void)seq_ids;  // block-layout KV: rows are addressed through block_table, not batch lines
   const mi_model_config& k = c->cfg;
   MI_CHECK(B >= 1 && B <= k.max_num_seqs, "batch size exceeds max_num_seqs");
@@ -766,6 +811,11 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
   hipStream_t s = c->stream;
   const int V = k.vocab_size;
   const int bs = k.block_size;
+  if (tokens_out && sampling_params)
+    for (int b = 0; b < B; ++b) {
+      const float tk = sampling_params[b * 3], tp = sampling_params[b * 3 + 1], tt = sampling_params[b * 3 + 2];
+      MI_CHECK(tk >= 1.f && tp > 0.f && tp <= 1.f && tt > 0.f, "sampling_params rows must be (top_k >= 1, 0 < top_p <= 1, temperature > 0)");
+    }
 
   auto check_row = [&](int b, int full, int n_new) -> int {
     MI_CHECK(full >= 1 && full <= k.max_model_len, "full_context_lens out of range");
@@ -775,6 +825,10 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
       const int64_t blk = block_table[(size_t)b * MB + j];
       MI_CHECK(blk >= 0 && blk < k.num_blocks, "block_table entry out of range inside the live context");
     }
+    return MI_OK;
+  };
+  auto push_inputs = [&]() -> int {   // the whole (25 KiB) input block in one copy
+    MI_HIP(hipMemcpyAsync(c->d_inputs, c->h_inputs, c->inputs_elems * 4, hipMemcpyHostToDevice, s));
     return MI_OK;
   };
 
@@ -792,15 +846,12 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
       c->h_ctx[b] = full;
       for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)block_table[(size_t)b * MB + j];
     }
-    MI_HIP(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_slots, c->h_slots, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_ctx, c->h_ctx, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_bt, c->h_bt, (size_t)B * MB * 4, hipMemcpyHostToDevice, s));
+    MI_TRY(push_inputs());
     MI_TRY(capture_or_launch_decode(c, B, MB));
     c->last_B = B;
     c->last_MB = MB;
-    MI_TRY(fetch_logits(c, B, logits_out));
+    if (tokens_out) MI_TRY(sample_on_device(c, B, 0, sampling_params, seed, tokens_out));
+    else MI_TRY(fetch_logits(c, B, logits_out));
     return prof_collect(c);
   }
 
@@ -823,14 +874,32 @@ int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const 
       c->h_slots[t] = (int32_t)slot;
     }
     for (int j = 0; j < MB; ++j) c->h_bt[j] = (int32_t)block_table[(size_t)b * MB + j];
-    MI_HIP(hipMemcpyAsync(c->d_ids, c->h_ids, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_pos, c->h_pos, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_slots, c->h_slots, (size_t)n_new * 4, hipMemcpyHostToDevice, s));
-    MI_HIP(hipMemcpyAsync(c->d_bt, c->h_bt, (size_t)MB * 4, hipMemcpyHostToDevice, s));
+    MI_TRY(push_inputs());
     MI_TRY(run_layers(c, n_new, false, 1, MB, comp, 1, n_new - 1));
-    MI_TRY(fetch_logits(c, 1, logits_out + (size_t)b * V));
+    // (the copy engine reads the pinned block asynchronously: the next row's staging must not
+    //  start before this row's copy has been consumed -- both fetch paths synchronize the stream)
+    if (tokens_out) MI_TRY(sample_on_device(c, 1, b, sampling_params, seed, tokens_out));
+    else MI_TRY(fetch_logits(c, 1, logits_out + (size_t)b * V));
   }
   return prof_collect(c);
+}
+
+int mi_forward(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const int64_t* position_ids,
+               const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
+               int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
+               float* logits_out) {
+  MI_CHECK(logits_out, "null argument");
+  return forward_impl(c, B, S, input_ids, position_ids, seq_ids, block_table, MB, slot_mapping, SM, full_context_lens,
+                      computed_context_lens, logits_out, nullptr, 0, nullptr);
+}
+
+int mi_forward_tokens(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids, const int64_t* position_ids,
+                      const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
+                      int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
+                      const float* sampling_params, uint64_t seed, int64_t* tokens_out) {
+  MI_CHECK(tokens_out, "null argument");
+  return forward_impl(c, B, S, input_ids, position_ids, seq_ids, block_table, MB, slot_mapping, SM, full_context_lens,
+                      computed_context_lens, nullptr, sampling_params, seed, tokens_out);
 }
 
 int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
@@ -916,6 +985,12 @@ int mi_tp_init_transport(mi_ctx* c, mi_allreduce_fn all_reduce, mi_allgather_fn 
 }
 
 // ---- per-kernel entry points ------------------------------------------------------------
+int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
+                 int32_t* tokens_out, void* stream) {
+  MI_CHECK(logits && tokens_out && B >= 1 && V >= 1, "bad argument");
+  return launch_sample_rows(logits, 1, B, V, B, sampling_params, seed, 0, tokens_out, (hipStream_t)stream);
+}
+
 int mi_op_quantize_weight(const float* w, int32_t N, int32_t K, int32_t wd, int32_t qt, void* tiled_out,
                           float* scale_out, void* stream) {
   MI_CHECK(w && tiled_out && scale_out, "null argument");

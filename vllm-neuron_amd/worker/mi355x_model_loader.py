@@ -60,6 +60,9 @@ class MI355XModelBase(nn.Module):
         self.architecture: str = ""
         self.num_key_value_heads: int = 0
         self.head_dim: int = 0
+        # on-device sampling: the draw for call n is a pure function of (seed, n, row)
+        self._sample_seed: int = 0
+        self._sample_calls: int = 0
 
     # the reference exposes the merged config as `.neuron_config`; keep that spelling alive
     @property
@@ -114,9 +117,6 @@ class MI355XCausalLM(MI355XModelBase):
         cfg = self.mi355x_config
         with self._reordered(input_block_ids, input_ids=input_ids, **kwargs) as (seq_ids, inputs, restore):
             ids = inputs["input_ids"]
-            if cfg.on_device_sampling_config:
-                raise NotImplementedError("on-device sampling is not implemented on MI355X yet; "
-                                          "leave on_device_sampling_config unset (CPU sampling)")
             if cfg.is_block_kv_layout:
                 block_table, slot_mapping = inputs["block_tables"], inputs["slot_mapping"]
             else:
@@ -129,6 +129,15 @@ class MI355XCausalLM(MI355XModelBase):
                 # contiguous KV: prefill computes everything, decode everything but the new token
                 full = inputs["full_context_lens"].reshape(-1)
                 computed = torch.zeros_like(full) if ids.shape[1] > 1 else full - 1
+            if cfg.on_device_sampling_config:
+                # the model returns sampled ids in place of logits (reference loader.py:350-356);
+                # sampling_params rows = (top_k, top_p, temperature), greedy rewritten to top_k = 1
+                self._sample_calls += 1
+                tokens = self.model.forward_tokens(ids, inputs["position_ids"], seq_ids, block_table, slot_mapping,
+                                                   inputs["full_context_lens"], computed,
+                                                   sampling_params=inputs.get("sampling_params"),
+                                                   seed=(self._sample_seed << 32) + self._sample_calls)
+                return restore(tokens)
             logits = self.model.forward(ids, inputs["position_ids"], seq_ids, block_table, slot_mapping,
                                         inputs["full_context_lens"], computed)
             return restore(logits)
@@ -315,8 +324,10 @@ def get_mi355x_model(model_config, cache_config, parallel_config, scheduler_conf
 def _get_default_mi355x_config(model_config, cache_config, parallel_config, scheduler_config,
                                lora_serving_config, speculative_config) -> dict:
     """Same keys and defaults as the reference's `_get_default_neuron_config`
-    (loader.py:725-793), except `on_device_sampling_config`, which defaults to None here:
-    the CPU-sampling path is the one this backend implements."""
+    (loader.py:725-793), except `on_device_sampling_config`, which defaults to None here (the
+    reference defaults to OnDeviceSamplingConfig(dynamic=True, deterministic=False)): CPU sampling
+    is the parity path of record; any truthy value (e.g. {"dynamic": True}) selects the on-device
+    sampler (mi_forward_tokens)."""
     if scheduler_config.chunked_prefill_enabled:
         batch_size = 1
         max_context_length = scheduler_config.max_num_batched_tokens

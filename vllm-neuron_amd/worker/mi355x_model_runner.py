@@ -144,8 +144,14 @@ class MI355XModelRunner:
     def _validate_sampling_configuration(self) -> None:
         try:
             if self.model.mi355x_config.on_device_sampling_config is not None:
-                raise NotImplementedError("on_device_sampling_config is set but on-device sampling is not "
-                                          "implemented on MI355X yet")
+                # hardware sampling (reference runner.py:208-228): ids come back from the model call
+                if not hasattr(self.model, "sample"):
+                    raise RuntimeError("Model does not have required 'sample' method for hardware sampling")
+                self.model._sample_seed = int(getattr(self.model_config, "seed", 0) or 0) & 0xFFFFFFFF
+                logger.info("On-device sampling enabled: config=%s (top_k <= %d, per-request seeds and "
+                            "logprobs are CPU-sampling features)", self.model.mi355x_config.on_device_sampling_config,
+                            self._MAX_DEVICE_SAMPLING_TOP_K)
+                return
             if self.cpu_sampler is None:
                 raise RuntimeError("CPU sampling is required but cpu_sampler is not initialized")
             if not hasattr(self.model, "sample"):
@@ -405,7 +411,8 @@ class MI355XModelRunner:
     def get_mi355x_sampling_params(self, input_ids: torch.Tensor) -> torch.Tensor:
         """Per-request (top_k, top_p, temperature) rows, packed like the reference's
         get_nxd_sampling_params (runner.py:1106-1140): greedy requests become (1, p, 1.0).
-        Unused by the CPU-sampling path; carried for the on-device sampling follow-up."""
+        Unused by the CPU-sampling path; consumed by mi_forward_tokens when
+        on_device_sampling_config is set."""
         n = self.scheduler_config.max_num_seqs
         max_topk = min(self.model_config.get_vocab_size(), self._MAX_DEVICE_SAMPLING_TOP_K)
         params = torch.ones(n, 3, dtype=torch.float32)
