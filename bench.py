@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--ttft-prompts", type=int, default=8, help="prompts per context-encoding bucket")
+    ap.add_argument("--ttft-prompts", type=int, default=32, help="prompts per context-encoding bucket (p50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weight-dtype", default="f8e4m3", choices=["f8e4m3", "int8", "bf16"])
     ap.add_argument("--bf16-prefill-activations", action="store_true",
@@ -182,12 +182,40 @@ def main():
         if rank == 0:
             print(f"[bench] ttft bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
 
-    # ---- decode: B sequences at context DECODE_CTX ------------------------------------------
+    # ---- the whole serving loop (scheduler -> runner -> library -> sampler), for the record: 4
+    #      requests of 900 prompt tokens decoding 128 tokens each, first with the CPU sampler (the
+    #      parity path: [B, V] fp32 logits cross PCIe every step), then with on-device sampling
+    #      (B ids cross).  Rates are of the decode phase; not the headline `value`.
+    def engine_decode_rate():
+        prompts = [torch.randint(0, hf.vocab_size, (900,), generator=g).tolist() for _ in range(MAX_NUM_SEQS)]
+        t_ = time.perf_counter()
+        outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=128))
+        dt = time.perf_counter() - t_
+        ntok = sum(len(o.token_ids) for o in outs)
+        first = max(o.ttft_s for o in outs)
+        return round((ntok - len(outs)) / (dt - first), 1)
+    engine_rates = {"cpu_sampling": engine_decode_rate()}
+    model_adapter = eng.worker.model_runner.model
+    model_adapter.mi355x_config.on_device_sampling_config = {"dynamic": True, "deterministic": False}
+    engine_rates["on_device_sampling"] = engine_decode_rate()
+    model_adapter.mi355x_config.on_device_sampling_config = None
+
+    # ---- decode at other context lengths (ctx 256 / 1024 / 2040), device-resident ---
     from tests.helpers import decode_inputs
     mb = MAX_MODEL_LEN // BLOCK_SIZE
     perm = (torch.randperm(PA_NUM_BLOCKS, generator=torch.Generator().manual_seed(2)) + 1).tolist()
     blocks = [perm[b * mb:(b + 1) * mb] for b in range(MAX_NUM_SEQS)]
     toks = torch.randint(0, hf.vocab_size, (MAX_NUM_SEQS,), generator=g).tolist()
+    by_ctx = {}
+    for ctx_len in (256, 2040):
+        inp_c = decode_inputs(toks, [ctx_len - 1] * MAX_NUM_SEQS, blocks, BLOCK_SIZE, MAX_MODEL_LEN)
+        for _ in range(2):
+            native.forward(**inp_c)
+        native.replay_decode(8)
+        n_c = max(args.steps // 2, 8)
+        by_ctx[str(ctx_len)] = round(MAX_NUM_SEQS * n_c / (native.replay_decode(n_c) * 1e-3), 1)
+
+    # ---- decode: B sequences at context DECODE_CTX ------------------------------------------
     inp = decode_inputs(toks, [DECODE_CTX - 1] * MAX_NUM_SEQS, blocks, BLOCK_SIZE, MAX_MODEL_LEN)
     for _ in range(2):
         native.forward(**inp)                            # captures the graph, leaves inputs resident
@@ -258,6 +286,8 @@ def main():
                                    f"max_model_len={MAX_MODEL_LEN}, buckets={BUCKETS}",
                        "parallelism": f"tp{world}", "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
             "ttft_p50_ms": ttft, "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
+            "engine_decode_tokens_per_s": engine_rates,
             "pcie_inclusive_tokens_per_s": round(MAX_NUM_SEQS / e2e, 2),
             "init_s": round(init_s, 2), "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -16,6 +16,7 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -221,6 +222,28 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
 }
 
+// Host-side stage timing of the token-generation call (MI355X_HOST_TIMING=1: printed at destroy).
+struct HostTiming {
+  bool on = getenv("MI355X_HOST_TIMING") != nullptr;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  long calls = 0;
+  std::chrono::steady_clock::time_point t0;
+  void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+  void lap(int i) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    acc[i] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t0 = t1;
+  }
+  void report() const {
+    if (!on || !calls) return;
+    fprintf(stderr, "[mi355x host timing] %ld decode calls, us/call: stage+validate %.1f | H2D enqueue %.1f | launch %.1f | "
+                    "sample/fetch enqueue %.1f | wait %.1f | copy-out %.1f\n", calls, acc[0] / calls, acc[1] / calls,
+            acc[2] / calls, acc[3] / calls, acc[4] / calls, acc[5] / calls);
+  }
+};
+static HostTiming g_ht;
+
 int all_reduce_partial(mi_ctx* c, int rows) {
   if (!c->collective()) return MI_OK;
   Scope sc(c, MI_K_COMM);
@@ -356,8 +379,11 @@ int fetch_logits(mi_ctx* c, int nrows, float* out) {
   const int V = k.vocab_size;
   if (!c->collective()) {
     MI_HIP(hipMemcpyAsync(c->h_logits, c->logits, (size_t)nrows * V * 4, hipMemcpyDeviceToHost, c->stream));
+    g_ht.lap(3);
     MI_HIP(hipStreamSynchronize(c->stream));
+    g_ht.lap(4);
     memcpy(out, c->h_logits, (size_t)nrows * V * 4);
+    g_ht.lap(5);
     return MI_OK;
   }
   const size_t per_rank = (size_t)k.max_num_seqs * c->V_l;
@@ -595,6 +621,7 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
 
 int mi_ctx_destroy(mi_ctx* c) {
   if (!c) return MI_OK;
+  g_ht.report();
   hipSetDevice(c->cfg.device_id);
   hipStreamSynchronize(c->stream);
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
@@ -791,8 +818,11 @@ static int sample_on_device(mi_ctx* c, int nrows, int row0, const float* samplin
     else MI_TRY(launch_sample_rows(c->logits, 1, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s));
   }
   MI_HIP(hipMemcpyAsync(c->h_tokens, c->d_tokens, (size_t)nrows * 4, hipMemcpyDeviceToHost, s));
+  g_ht.lap(3);
   MI_HIP(hipStreamSynchronize(s));
+  g_ht.lap(4);
   for (int i = 0; i < nrows; ++i) tokens_out[row0 + i] = c->h_tokens[i];
+  g_ht.lap(5);
   return MI_OK;
 }
 
@@ -833,6 +863,7 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
   };
 
   if (S == 1) {  // ---- token generation -------------------------------------------------
+    g_ht.start();
     for (int b = 0; b < B; ++b) {
       const int full = (int)full_context_lens[b];
       MI_TRY(check_row(b, full, 1));
@@ -846,12 +877,16 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
       c->h_ctx[b] = full;
       for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)block_table[(size_t)b * MB + j];
     }
+    g_ht.lap(0);
     MI_TRY(push_inputs());
+    g_ht.lap(1);
     MI_TRY(capture_or_launch_decode(c, B, MB));
+    g_ht.lap(2);
     c->last_B = B;
     c->last_MB = MB;
     if (tokens_out) MI_TRY(sample_on_device(c, B, 0, sampling_params, seed, tokens_out));
     else MI_TRY(fetch_logits(c, B, logits_out));
+    g_ht.calls += 1;
     return prof_collect(c);
   }
 
