@@ -171,16 +171,32 @@ def main():
 
     # ---- p50 TTFT per bucket, through scheduler -> runner -> library -> CPU sampler ----------
     g = torch.Generator().manual_seed(0)
-    ttft = {}
-    for bucket in BUCKETS:
-        samples = []
-        for _ in range(args.ttft_prompts + 1):           # first one is warm-up
-            prompt = torch.randint(0, hf.vocab_size, (bucket - 17,), generator=g).tolist()
-            out = eng.generate([prompt], SamplingParams(temperature=0.0, max_tokens=1))[0]
-            samples.append(out.ttft_s * 1e3)
-        ttft[str(bucket)] = round(statistics.median(samples[1:]), 3)
-        if rank == 0:
-            print(f"[bench] ttft bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
+
+    def ttft_sweep(engine, tag):
+        res = {}
+        for bucket in BUCKETS:
+            samples = []
+            for _ in range(args.ttft_prompts + 1):           # first one is warm-up
+                prompt = torch.randint(0, hf.vocab_size, (bucket - 17,), generator=g).tolist()
+                out = engine.generate([prompt], SamplingParams(temperature=0.0, max_tokens=1))[0]
+                samples.append(out.ttft_s * 1e3)
+            res[str(bucket)] = round(statistics.median(samples[1:]), 3)
+            if rank == 0:
+                print(f"[bench] ttft {tag} bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
+        return res
+    ttft = ttft_sweep(eng, "fp8xfp8" if override.get("prefill_fp8_activations") else "weight-only")
+    # the other context-encoding numerics mode, for the record: FP8 weights x bf16 activations on the
+    # bf16 MFMA (what the reference's weight-only quantized linears compute); one more engine
+    ttft_wo = None
+    if override.get("prefill_fp8_activations") and world == 1:
+        o2 = dict(override)
+        o2["prefill_fp8_activations"] = False
+        eng2 = MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
+                            num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True,
+                            tensor_parallel_size=world, override_mi355x_config=o2, rank=rank, local_rank=local_rank)
+        ttft_wo = ttft_sweep(eng2, "weight-only")
+        eng2.worker.model_runner.model.model.close()
+        del eng2
 
     # ---- the whole serving loop (scheduler -> runner -> library -> sampler), for the record: 4
     #      requests of 900 prompt tokens decoding 128 tokens each, first with the CPU sampler (the
@@ -285,7 +301,7 @@ def main():
                                    f"ctx={DECODE_CTX}, block_size={BLOCK_SIZE}, pa_num_blocks={PA_NUM_BLOCKS}, "
                                    f"max_model_len={MAX_MODEL_LEN}, buckets={BUCKETS}",
                        "parallelism": f"tp{world}", "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
-            "ttft_p50_ms": ttft, "device_ms_per_step": round(dev_ms / args.steps, 4),
+            "ttft_p50_ms": ttft, "ttft_p50_ms_bf16_activations": ttft_wo, "device_ms_per_step": round(dev_ms / args.steps, 4),
             "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
             "engine_decode_tokens_per_s": engine_rates,
             "pcie_inclusive_tokens_per_s": round(MAX_NUM_SEQS / e2e, 2),

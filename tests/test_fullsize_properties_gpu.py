@@ -1,0 +1,137 @@
+"""Parity at BASELINE.json's full size (Llama-3.1-8B shapes: 32 layers, H 4096, 32/8 heads x 128,
+I 14336, V 128256, FP8 per-channel weights, block_size 32, max_num_seqs 4, max_model_len 2048),
+where the CPU oracle would take hours: size-independent properties of the call contract that hold
+for ANY weights, checked on seeded synthetic weights generated on the device.
+
+  exact (bit-for-bit)
+    * a model call does not depend on WHICH physical blocks hold the context (block permutation);
+    * rows of a token-generation batch are independent: the same sequence in four rows gives four
+      identical logit rows (the B = 1 call agrees within tolerance: its context split differs);
+    * a replayed hipGraph step equals the eagerly launched one; repeating a step is idempotent;
+    * on-device greedy ids == argmax of the logits the CPU-sampling call returns.
+  within the stated tolerance (different kernels compute the same quantity)
+    * teacher forcing: the logits of position N-1 from context encoding of N tokens == those of
+      a token-generation step after context encoding of N-1 tokens (GEMM + MFMA flash attention
+      vs GEMV + split-context decode attention);
+    * a prefix-cache hit (computed_context_lens = 256) == encoding the full prompt;
+    * (characterisation) the MX FP8 x FP8 context-encoding mode computes the same function as
+      weight-only FP8 up to its activation-quantization noise.
+Tolerance: logits here have std 1.28, |max| 5.7.  Two kernel families that round the activations
+to bf16 at the same points but sum in different orders drift apart over 32 layers by 0.024 rms /
+0.11 max over the 128256 logits (measured); the bar is 0.04 rms and 0.16 max (~3 % of the logit
+range), and the top-1 id must agree unless the top-2 gap is inside that band.
+"""
+import pytest
+import torch
+
+from tests.helpers import decode_inputs, prefill_inputs
+
+pytestmark = pytest.mark.gpu
+
+BS, MAXLEN, NSEQ, NB = 32, 2048, 4, 4096 + 1
+MB = MAXLEN // BS
+TOL_MAX, TOL_RMS = 0.16, 0.04
+
+
+def _close(a, b):
+    d = (a - b).float()
+    return d.abs().max().item() <= TOL_MAX and d.pow(2).mean().sqrt().item() <= TOL_RMS
+
+
+def _model(a8=0, use_graphs=1):
+    from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+    m = NativeModel(num_layers=32, hidden_size=4096, num_heads=32, num_kv_heads=8, head_dim=128,
+                    intermediate_size=14336, vocab_size=128256, rms_norm_eps=1e-5, rope_theta=500000.0,
+                    rope_type=1, rope_factor=8.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0,
+                    rope_original_max_position=8192, qkv_bias=0, tie_word_embeddings=0,
+                    num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
+                    weight_dtype=MI_W["f8e4m3"], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
+                    tp_degree=1, tp_rank=0, device_id=0, use_graphs=use_graphs, ctx_buckets=[256, 512, 1024, 2048],
+                    prefill_fp8_activations=a8)
+    m.init_synthetic_weights(1, 0.02)
+    m.finalize()
+    return m
+
+
+@pytest.fixture(scope="module")
+def model():
+    m = _model()
+    yield m
+    m.close()
+
+
+def _blocks(seed, n=MB):
+    return (torch.randperm(NB - 1, generator=torch.Generator().manual_seed(seed)) + 1)[:n].tolist()
+
+
+def _prompt(n, seed=0):
+    return torch.randint(0, 128256, (n,), generator=torch.Generator().manual_seed(seed)).tolist()
+
+
+def test_block_permutation_invariance_and_idempotence(model):
+    p = _prompt(700)
+    a = model.forward(**prefill_inputs(p, _blocks(1), BS, MAXLEN, 0))
+    b = model.forward(**prefill_inputs(p, _blocks(2), BS, MAXLEN, 0))
+    c = model.forward(**prefill_inputs(p, _blocks(2), BS, MAXLEN, 0))
+    assert torch.isfinite(a).all() and a.std() > 0.1
+    assert torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_teacher_forcing_encoding_equals_generation(model):
+    for n in (300, 1025):
+        p = _prompt(n, seed=n)
+        blocks = _blocks(3)
+        full = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))           # logits at position n-1
+        model.forward(**prefill_inputs(p[:-1], blocks, BS, MAXLEN, 0))             # KV for 0..n-2
+        step = model.forward(**decode_inputs([p[-1]], [n - 1], [blocks], BS, MAXLEN))
+        assert _close(full, step), (n, (full - step).abs().max().item())
+        assert int(full.argmax()) == int(step.argmax()) or full.topk(2).values.diff().abs().item() < TOL_MAX
+
+
+def test_prefix_cache_hit_equals_full_encoding(model):
+    p = _prompt(900, seed=5)
+    blocks = _blocks(4)
+    full = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))
+    hit = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 256))              # blocks 0..7 already hold the prefix
+    assert _close(full, hit)
+
+
+def test_batch_rows_are_independent_and_graph_replay_is_exact(model):
+    n = 513
+    p = _prompt(n, seed=9)
+    perm = _blocks(10, NSEQ * MB)                   # disjoint physical blocks per row
+    rows = [perm[i * MB:(i + 1) * MB] for i in range(NSEQ)]
+    for blocks in rows:
+        model.forward(**prefill_inputs(p[:-1], blocks, BS, MAXLEN, 0))
+    inp4 = decode_inputs([p[-1]] * NSEQ, [n - 1] * NSEQ, rows, BS, MAXLEN)
+    first = model.forward(**inp4)                   # eager launches (and the capture) for this shape
+    again = model.forward(**inp4)                   # graph replay
+    assert torch.equal(first, again)
+    for r in range(1, NSEQ):
+        assert torch.equal(first[0], first[r]), r
+    one = model.forward(**decode_inputs([p[-1]], [n - 1], [rows[2]], BS, MAXLEN))
+    assert _close(one[0], first[2])                 # B = 1 splits the context differently: same value, other summation order
+    assert model.forward_tokens(**inp4).tolist() == first.argmax(dim=1).tolist()
+
+
+def test_fp8_activation_mode_is_the_same_function_up_to_its_quantization_noise():
+    """Characterisation, not parity (the rule itself is pinned against the oracle on the small
+    models): per-token e4m3 activations carry 3 mantissa bits (3.6 % rms per element) into every
+    GEMM of 32 layers.  On these UNSTRUCTURED random weights that noise reaches the logits almost
+    undamped -- measured 0.31-0.49 rms against a logit std of 1.28 (cosine 0.92-0.97), far more
+    than on trained checkpoints -- so the check is only that the two modes compute the same
+    function: strongly correlated logits, no blow-up, deterministic."""
+    m8 = _model(a8=1)
+    ref = _model(a8=0)
+    p = _prompt(600, seed=11)
+    blocks = _blocks(20)
+    a = m8.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))
+    a2 = m8.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))
+    b = ref.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))
+    assert torch.equal(a, a2) and torch.isfinite(a).all()
+    cos = torch.nn.functional.cosine_similarity(a, b).item()
+    rms = (a - b).pow(2).mean().sqrt().item()
+    assert cos > 0.9 and rms < 0.5 * b.std().item(), (cos, rms)
+    assert abs(a.std().item() / b.std().item() - 1) < 0.1
+    m8.close()
+    ref.close()
