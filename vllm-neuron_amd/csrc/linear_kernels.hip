@@ -655,15 +655,30 @@ int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, con
 // straight from the pre-tiled global image.
 constexpr int kBM = 128, kBN = 128, kBK = 64;
 
-template <int WD, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
-                                                   const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
+// SPLIT: grid.z K-slices write raw fp32 accumulators to slab[z][m][n] (see gemm_a8_kernel).
+// Registers are kept under 170 per lane so that three work-groups share a CU (the same lesson as
+// the FP8 GEMM): the weight tiles of a K-step are decoded once into their A fragments, the raw
+// registers are refilled with the next K-step's tiles straight away, and the activation
+// fragments are read per 16-token tile instead of all at once.
+template <int WD, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WD == MI_W_BF16 ? 2 : 3, WD == MI_W_BF16 ? 2 : 3))) void gemm_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
+                                                   const uint16_t* __restrict__ x, int ldx, EpiArgs e,
+                                                   float* __restrict__ slab) {
   __shared__ __attribute__((aligned(16))) uint4 xs[kBM * 8];  // 16 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   const int wn = wave >> 1, wm = wave & 1;
-  const int m0 = blockIdx.x * kBM, nt0 = blockIdx.y * (kBN / 16) + wn * 4;
-  const int nks = K / kBK;
+  // XCD-aware tile order (see gemm_a8_kernel): XCD = linear id % 8 owns every eighth weight slab
+  // and walks all token blocks of a slab back to back
+  const int mtiles = ceil_div(T, kBM), ntiles = ceil_div(NT, kBN / 16);
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
+  if (nblk >= ntiles) return;
+  const int m0 = mblk * kBM, nt0 = nblk * (kBN / 16) + wn * 4;
+  const int nks_all = K / kBK;
+  const int ks_per = SPLIT ? ceil_div(nks_all, (int)gridDim.z) : nks_all;
+  const int ks_beg = SPLIT ? (int)blockIdx.z * ks_per : 0;
+  const int nks = min(ks_beg + ks_per, nks_all);
   constexpr int WPK = (WD == MI_W_BF16) ? 2 : 1;  // weight tiles per K-step
 
   f32x4_t acc[4][4];
@@ -674,70 +689,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint4* __restrict__ W, 
 
   // x staging: thread -> rows (tid/8 + 32 i), 16-byte chunk tid%8
   const int srow = tid >> 3, sch = tid & 7;
-  uint4 xr[4];
-  uint4 wr[4][WPK], wnx[4][WPK];
+  u32x4_t xr[4], wr[4][WPK];
   auto load_x = [&](int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + srow + 32 * i;
-      xr[i] = (m < T) ? *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + ks * kBK + sch * 8)
-                      : make_uint4(0, 0, 0, 0);
+      const int m = min(m0 + srow + 32 * i, T - 1);   // rows past T: a copy of the last row, never stored
+      xr[i] = *reinterpret_cast<const u32x4_t*>(x + (size_t)m * ldx + ks * kBK + sch * 8);
     }
   };
-  auto load_w = [&](uint4 (&dst)[4][WPK], int ks) {
+  auto load_w = [&](int ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int t = 0; t < WPK; ++t)
-        dst[i][t] = (nt0 + i < NT) ? W[((size_t)(nt0 + i) * KT + ks * WPK + t) * 64 + lane] : make_uint4(0, 0, 0, 0);
+        wr[i][t] = *reinterpret_cast<const u32x4_t*>(W + ((size_t)min(nt0 + i, NT - 1) * KT + ks * WPK + t) * 64 + lane);
   };
 
-  load_x(0);
-  load_w(wr, 0);
-  for (int ks = 0; ks < nks; ++ks) {
+  if (ks_beg < nks) {
+    load_x(ks_beg);
+    load_w(ks_beg);
+  }
+  for (int ks = ks_beg; ks < nks; ++ks) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = srow + 32 * i;
-      xs[r * 8 + (sch ^ (r & 7))] = xr[i];
+      *reinterpret_cast<u32x4_t*>(&xs[r * 8 + (sch ^ (r & 7))]) = xr[i];
+    }
+    bf16x8_t a0[4], a1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (WD == MI_W_BF16) {
+        a0[i] = __builtin_bit_cast(bf16x8_t, wr[i][0]);
+        a1[i] = __builtin_bit_cast(bf16x8_t, wr[i][1]);
+      } else {
+        const u32x4_t w4 = wr[i][0];
+        a0[i] = decode8<WD>(w4[0], w4[1]);
+        a1[i] = decode8<WD>(w4[2], w4[3]);
+      }
     }
     __syncthreads();
-    if (ks + 1 < nks) {
+    if (ks + 1 < nks) {      // the raw registers are free again: next K-step's operands
       load_x(ks + 1);
-      load_w(wnx, ks + 1);
+      load_w(ks + 1);
     }
-    bf16x8_t bfr[4][2];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int r = wm * 64 + mt * 16 + c;
+      const int ch0 = (WD == MI_W_BF16) ? g : 2 * g, ch1 = (WD == MI_W_BF16) ? 4 + g : 2 * g + 1;
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch0 ^ (r & 7))]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch1 ^ (r & 7))]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int ch = (WD == MI_W_BF16) ? (4 * s + g) : (2 * g + s);
-        bfr[mt][s] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch ^ (r & 7))]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16x8_t a0, a1;
-      if constexpr (WD == MI_W_BF16) {
-        a0 = __builtin_bit_cast(bf16x8_t, wr[i][0]);
-        a1 = __builtin_bit_cast(bf16x8_t, wr[i][1]);
-      } else {
-        a0 = decode8<WD>(wr[i][0].x, wr[i][0].y);
-        a1 = decode8<WD>(wr[i][0].z, wr[i][0].w);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[mt][0], acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[mt][1], acc[i][mt], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0, acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1, acc[i][mt], 0, 0, 0);
       }
     }
     __syncthreads();
-    if (ks + 1 < nks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < WPK; ++t) wr[i][t] = wnx[i][t];
-    }
   }
 
 #pragma unroll
@@ -746,32 +753,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(const uint4* __restrict__ W, 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int m = m0 + wm * 64 + mt * 16 + c;
-      if (m < T) epilogue<EPI>(e, m, (nt0 + i) * 16 + g * 4, acc[i][mt]);
+      if (m >= T) continue;
+      const int n0 = (nt0 + i) * 16 + g * 4;
+      if constexpr (SPLIT) {
+        *reinterpret_cast<float4*>(slab + ((size_t)blockIdx.z * T + m) * (NT * 16) + n0) =
+            make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+      } else {
+        epilogue<EPI>(e, m, n0, acc[i][mt]);
+      }
     }
   }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int KS, int T, int N, EpiArgs e);
+
+// K-split for grids too small to occupy the chip (768 work-groups are resident at once): below 256
+// tiles aim for 512 work-groups, below 384 for 768 (rule measured on the FP8 GEMM).
+static int gemm_pick_splitk(int tiles, int nks, int T, int N, size_t ws_bytes) {
+  if (!ws_bytes || tiles >= 384) return 1;
+  int KS = min(min(8, nks), ceil_div(tiles < 256 ? 512 : 768, tiles));
+  while (KS > 1 && (size_t)KS * T * N * sizeof(float) > ws_bytes) --KS;
+  return KS;
+}
+
 template <int WD>
-static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                          float* splitk_ws, size_t splitk_ws_bytes) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
-  dim3 grid(ceil_div(T, kBM), ceil_div(w.N, kBN));
+  const int mtiles = ceil_div(T, kBM), ntiles = ceil_div(w.N, kBN);
+  const int KS = gemm_pick_splitk(mtiles * ntiles, w.K / kBK, T, w.N, splitk_ws ? splitk_ws_bytes : 0);
+  dim3 grid(8 * mtiles * ceil_div(ntiles, 8), 1, KS);
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
-  if (epi == EPI_QKV) hipLaunchKernelGGL((gemm_kernel<WD, EPI_QKV>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
-  else if (epi == EPI_SWIGLU) hipLaunchKernelGGL((gemm_kernel<WD, EPI_SWIGLU>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
-  else if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_kernel<WD, EPI_RESID>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
-  else hipLaunchKernelGGL((gemm_kernel<WD, EPI_F32>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e);
+#define MI_G(EPI_) \
+  do { \
+    if (KS == 1) { \
+      hipLaunchKernelGGL((gemm_kernel<WD, EPI_, false>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e, nullptr); \
+    } else { \
+      hipLaunchKernelGGL((gemm_kernel<WD, EPI_, true>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e, splitk_ws); \
+      hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+    } \
+  } while (0)
+  if (epi == EPI_QKV) MI_G(EPI_QKV);
+  else if (epi == EPI_SWIGLU) MI_G(EPI_SWIGLU);
+  else if (epi == EPI_RESID) MI_G(EPI_RESID);
+  else MI_G(EPI_F32);
+#undef MI_G
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
 
-int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                float* splitk_ws, size_t splitk_ws_bytes) {
   MI_CHECK(T >= 1, "gemm: T must be >= 1");
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemm: N % 16 == 0 and K % 64 == 0 required");
   MI_CHECK(ldx % 8 == 0, "gemm: x row stride must be a multiple of 8 elements");
   switch (w.wd) {
-    case MI_W_BF16: return launch_gemm_wd<MI_W_BF16>(w, T, x, ldx, epi, e, s);
-    case MI_W_F8E4M3: return launch_gemm_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s);
-    case MI_W_INT8: return launch_gemm_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s);
+    case MI_W_BF16: return launch_gemm_wd<MI_W_BF16>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
+    case MI_W_F8E4M3: return launch_gemm_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
+    case MI_W_INT8: return launch_gemm_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
   }
   set_error("gemm: bad weight dtype");
   return MI_EINVAL;
@@ -932,15 +972,10 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
   const int bn = 64 * ntw;
   const int mtiles = ceil_div(T, kA8BM), ntiles = ceil_div(w.N, bn);
   // K-split only when the tile grid cannot occupy the chip and the slabs stay small
-  int KS = 1;
   // (768 work-groups are resident at once.  Measured on the Llama-8B shapes: below 256 tiles aim
   // for 512 work-groups, below 384 for 768; splitting larger grids costs more in slab traffic
   // than it wins -- 6.2 / 8.8 / 13.5 ms for the 256 / 512 / 1024 buckets.)
-  const int tiles = mtiles * ntiles;
-  if (splitk_ws && tiles < 384) {
-    KS = min(min(8, nks), ceil_div(tiles < 256 ? 512 : 768, tiles));
-    while (KS > 1 && (size_t)KS * T * w.N * sizeof(float) > splitk_ws_bytes) --KS;
-  }
+  const int KS = gemm_pick_splitk(mtiles * ntiles, nks, T, w.N, splitk_ws ? splitk_ws_bytes : 0);
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
   dim3 grid(8 * mtiles * ceil_div(ntiles, 8), 1, KS);   // see the kernel: XCD-aware tile order
 #define MI_A8(EPI_) \

@@ -219,7 +219,7 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
     return launch_gemm_a8(L.view(), rows, c->x8, rows, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
   }
   Scope sc(c, MI_K_GEMM);
-  return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream);
+  return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
 }
 
 // Host-side stage timing of the token-generation call (MI355X_HOST_TIMING=1: printed at destroy).
@@ -761,9 +761,9 @@ int mi_finalize(mi_ctx* c) {
   if (k.prefill_fp8_activations) {
     MI_TRY(dmalloc(&c->x8, R * std::max(std::max(c->H, c->I_l), c->q_dim), ws));
     MI_TRY(dmalloc(&c->x8_scale, R, ws));
-    c->splitk_ws_bytes = (size_t)64 << 20;
-    MI_TRY(dmalloc(&c->splitk_ws, c->splitk_ws_bytes / 4, ws));
   }
+  c->splitk_ws_bytes = (size_t)64 << 20;   // fp32 K-slice slabs of the short-prompt GEMMs
+  MI_TRY(dmalloc(&c->splitk_ws, c->splitk_ws_bytes / 4, ws));
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
   if (c->collective()) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
   MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
