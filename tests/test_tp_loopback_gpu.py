@@ -111,12 +111,15 @@ def test_sharded_ranks_match_oracle(name, tp, weight_dtype, quant_type):
     loop = Loopback(tp, _native.load_library())
     models = [_rank_model(cfg, w, tp, r, loop, weight_dtype, quant_type) for r in range(tp)]
     got = [[None] * len(steps) for _ in range(tp)]
+    toks = [None] * tp
     errs = []
 
     def run(rank):
         try:
             for i, (_, inp, _) in enumerate(steps):
                 got[rank][i] = models[rank].forward(**inp)
+            # on-device sampling over the vocab-parallel logits (ids come from the gathered segments)
+            toks[rank] = models[rank].forward_tokens(**steps[-1][1]).tolist()
         except Exception as e:                        # noqa: BLE001  (surface it in the main thread)
             errs.append((rank, e))
             loop.barrier.abort()
@@ -128,7 +131,8 @@ def test_sharded_ranks_match_oracle(name, tp, weight_dtype, quant_type):
         t.join(timeout=300)
     assert not errs, errs
     assert not any(t.is_alive() for t in threads)
-    assert all(n == len(steps) * 2 * cfg.num_layers for n in loop.calls)
+    assert all(n == (len(steps) + 1) * 2 * cfg.num_layers for n in loop.calls)
+    assert all(t == got[0][-1].argmax(dim=1).tolist() for t in toks), toks
     for i, ref in enumerate(want):
         a = got[0][i]
         for r in range(1, tp):
