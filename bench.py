@@ -48,13 +48,14 @@ DECODE_CTX = 1024
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def weight_bytes_per_step(hf, tp):
-    """Algorithmic weight bytes ONE GPU streams per token-generation step (fp8 = 1 B/param)."""
+def weight_bytes_per_step(hf, tp, bytes_per_param=1):
+    """Algorithmic weight bytes ONE GPU streams per token-generation step (fp8 / int8 = 1 B per
+    parameter, bf16 = 2)."""
     H, I, V, L = hf["hidden_size"], hf["intermediate_size"], hf["vocab_size"], hf["num_hidden_layers"]
     qd = hf["num_attention_heads"] * hf["head_dim"]
     kvd = hf["num_key_value_heads"] * hf["head_dim"]
     per_layer = (qd + 2 * kvd) * H + H * qd + 2 * I * H + H * I
-    return (L * per_layer + V * H) / tp
+    return (L * per_layer + V * H) * bytes_per_param / tp
 
 
 def kv_bytes_per_step(hf, tp, B, ctx):
@@ -264,7 +265,7 @@ def main():
     native.profile_enable(False)
     gemv_ms, gemv_n = prof["ms"]["gemv"], prof["launches"]["gemv"]
     achieved = prof["gemv_weight_bytes"] / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
-    step_bytes = weight_bytes_per_step(LLAMA31_8B, world) + kv_bytes_per_step(LLAMA31_8B, world, MAX_NUM_SEQS, DECODE_CTX)
+    step_bytes = weight_bytes_per_step(LLAMA31_8B, world, 2 if args.weight_dtype == "bf16" else 1) + kv_bytes_per_step(LLAMA31_8B, world, MAX_NUM_SEQS, DECODE_CTX)
     # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
     # gfx950-corrected; tests/pmc_summary.py) -- counters cannot be read from inside the process
     traffic, traffic_src = None, None
