@@ -830,7 +830,7 @@ int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, co
 // per SIMD); W fragments come straight from global (every wave reads distinct rows), x8 goes
 // through LDS; the next K-step's operands are fetched into registers under the MFMAs.
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-constexpr int kA8BM = 128, kA8BN = 256, kA8BK = 128;
+constexpr int kA8BM = 128, kA8BK = 128;   // tile: (64 NTW) weight rows x 128 tokens x 128 K bytes
 constexpr int kA8Pitch = kA8BK + 16;   // LDS row pitch in bytes (+16: rows start 4 banks apart)
 
 // SPLIT: grid.z K-slices each write their raw fp32 accumulators to slab[z][m][n]; splitk_reduce
