@@ -92,3 +92,69 @@ def test_random_call_sequences_match_oracle(seed):
             s["tokens"].append(int(row.argmax()))
     assert worst < 0.06, (name, wd, qt, bs, worst)
     model.close()
+
+
+@pytest.mark.parametrize("name,wd", [("llama31_like", "f8e4m3"), ("qwen25_like", "int8"), ("tinyllama_like", "bf16")])
+def test_wide_decode_batches_match_oracle(name, wd):
+    """Token-generation batches of 5..16 rows (the GEMV's general staging path: more than four
+    rows per norm prologue) against the oracle."""
+    bs, maxlen, nseq = 32, 256, 16
+    mb = maxlen // bs
+    nb = 1 + nseq * mb
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=2)
+    qt = "per_channel_symmetric"
+    quant = None if wd == "bf16" else dict(quantized=True, quantization_dtype=wd, quantization_type=qt)
+    oracle = PagedDecoderOracle(cfg, w, nb, bs, compute="bf16", quant=quant)
+    model = _native(cfg, w, wd, qt, bs, maxlen, nseq, nb)
+    g = torch.Generator().manual_seed(3)
+    blocks = [[1 + i * mb + j for j in range(mb)] for i in range(nseq)]
+    seqs, worst = [], 0.0
+    for i in range(nseq):
+        p = torch.randint(0, cfg.vocab_size, (3 + 11 * i,), generator=g).tolist()
+        inp = prefill_inputs(p, blocks[i], bs, maxlen, 0)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got - ref).abs().max().item())
+        seqs.append(p + [int(ref.argmax())])
+    for B in (16, 9, 5, 13):
+        rows = list(range(B))
+        inp = decode_inputs([seqs[i][-1] for i in rows], [len(seqs[i]) - 1 for i in rows], [blocks[i] for i in rows], bs, maxlen)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got - ref).abs().max().item())
+        for i, row in zip(rows, ref):
+            seqs[i].append(int(row.argmax()))
+    assert worst < 0.06, worst
+    model.close()
+
+
+def test_wide_hidden_size_matches_oracle():
+    """hidden_size 8192 (the Llama-3.3-70B width of BASELINE config 5): more 16-byte chunks per
+    activation row than threads in a GEMV work-group, a 64 KiB LDS image at B = 4, K = 8192 GEMMs."""
+    from oracle.paged_decoder import DecoderConfig
+    cfg = DecoderConfig(num_layers=1, hidden_size=8192, num_heads=8, num_kv_heads=1, head_dim=128,
+                        intermediate_size=512, vocab_size=512, rms_norm_eps=1e-5, rope_theta=500000.0)
+    bs, maxlen, nseq = 32, 128, 4
+    mb = maxlen // bs
+    nb = 1 + nseq * mb
+    w = make_weights(cfg, seed=4)
+    wd, qt = "f8e4m3", "per_channel_symmetric"
+    oracle = PagedDecoderOracle(cfg, w, nb, bs, compute="bf16",
+                                quant=dict(quantized=True, quantization_dtype=wd, quantization_type=qt))
+    model = _native(cfg, w, wd, qt, bs, maxlen, nseq, nb)
+    g = torch.Generator().manual_seed(6)
+    blocks = [[1 + i * mb + j for j in range(mb)] for i in range(nseq)]
+    seqs, worst, scale = [], 0.0, 0.0
+    for i in range(nseq):
+        p = torch.randint(0, cfg.vocab_size, (5 + 20 * i,), generator=g).tolist()
+        inp = prefill_inputs(p, blocks[i], bs, maxlen, 0)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst, scale = max(worst, (got - ref).abs().max().item()), max(scale, ref.abs().max().item())
+        seqs.append(p + [int(ref.argmax())])
+    for _ in range(3):
+        inp = decode_inputs([s[-1] for s in seqs], [len(s) - 1 for s in seqs], blocks, bs, maxlen)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got - ref).abs().max().item())
+        for s, row in zip(seqs, ref):
+            s.append(int(row.argmax()))
+    assert worst < 0.015 * max(scale, 4.0), (worst, scale)      # the 0.06-on-O(4) bar, scaled to these logits
+    model.close()
