@@ -54,9 +54,9 @@ __device__ __forceinline__ void epilogue(const EpiArgs& e, int m, int n0, f32x4_
 // retires in order: a late scale load would drain the whole prefetch).
 template <int EPI>
 __device__ __forceinline__ void epilogue_lds(const EpiArgs& e, int m, int n0, const float* sc4, const float* b4,
-                                             f32x4_t v) {
+                                             f32x4_t v, float rmul = 1.f) {
   const float4 sc = *reinterpret_cast<const float4*>(sc4);
-  v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+  v[0] *= sc.x * rmul; v[1] *= sc.y * rmul; v[2] *= sc.z * rmul; v[3] *= sc.w * rmul;
   if (b4) {
     const float4 b = *reinterpret_cast<const float4*>(b4);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -141,10 +141,10 @@ __device__ __forceinline__ void epi_prefetch_dependent(const EpiArgs& e, int n0,
 // epilogue_lds with the prefetched operands
 template <int EPI>
 __device__ __forceinline__ void epilogue_pre(const EpiArgs& e, int m, int n0, const float* sc4, const float* b4,
-                                             f32x4_t v, const EpiPre<EPI>& p) {
+                                             f32x4_t v, const EpiPre<EPI>& p, float rmul = 1.f) {
   if constexpr (EPI == EPI_RESID || EPI == EPI_QKV) {
     const float4 sc = *reinterpret_cast<const float4*>(sc4);
-    v[0] *= sc.x; v[1] *= sc.y; v[2] *= sc.z; v[3] *= sc.w;
+    v[0] *= sc.x * rmul; v[1] *= sc.y * rmul; v[2] *= sc.z * rmul; v[3] *= sc.w * rmul;
     if (b4) {
       const float4 b = *reinterpret_cast<const float4*>(b4);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -172,21 +172,21 @@ __device__ __forceinline__ void epilogue_pre(const EpiArgs& e, int m, int n0, co
       }
     }
   } else {
-    epilogue_lds<EPI>(e, m, n0, sc4, b4, v);
+    epilogue_lds<EPI>(e, m, n0, sc4, b4, v, rmul);
   }
 }
 
 // =====================================================================================
 // GEMV (token generation)
 // =====================================================================================
-// LDS: [x fragments: K/8 chunks * M * 16 B][zero slot 16 B][red: 2 * WAVES * 64 lanes * 16 B][scales][biases]
+// LDS: [x fragments: K/8 chunks * M * 16 B][zero slot 16 B][red: 2 * WAVES * 64 lanes * 16 B][scales][biases][sums of squares]
 constexpr int kGemvWaves = 8;
 constexpr int kGemvU = 8;  // 1 KiB loads per batch; two batches in flight per wave
 
 constexpr int kGemvMaxTilesPerWg = 64;  // row-tiles one work-group may own (scale/bias cache)
 size_t gemv_lds_bytes(int M, int K) {
-  // x image, zero slot, reduction buffers, scale + bias cache
-  return (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16 + 2 * kGemvMaxTilesPerWg * 16 * 4;
+  // x image, zero slot, reduction buffers, scale + bias cache, per-wave sums of squares [16 rows][16]
+  return (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16 + 2 * kGemvMaxTilesPerWg * 16 * 4 + 16 * 16 * 4;
 }
 bool gemv_fits(int M, int K) { return M <= 16 && gemv_lds_bytes(M, K) <= 160 * 1024; }
 
@@ -297,46 +297,44 @@ __device__ __forceinline__ void gemv_pro_finish(const ProArgs& p, int M, int K, 
       xf[xfrag_slot<WD>(c8, m, M)] = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)c8 * 8);
     }
   } else {
-    const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if constexpr (PRO == PRO_NORM_PARTIAL) h[r][e] += pv[r][e];
-        ss[r] += h[r][e] * h[r][e];
+        ss[r] = __builtin_fmaf(h[r][e], h[r][e], ss[r]);   // one fixed fma chain per row: identical rows -> identical bits
       }
       if (tid >= nchunk) ss[r] = 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float t = wave_sum(ss[r]);
-      if (lane == 0) red_f[r * 16 + wave] = t;
+      if (lane == 0) red_f[r * 16 + wave] = t;     // read after the staging barrier (gemv_row_rinv)
     }
-    __syncthreads();
     if (tid < nchunk) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float tot = 0.f;
-        for (int w = 0; w < nw; ++w) tot += red_f[r * 16 + w];
-        if (r < M) gemv_emit_row<WD>(p, M, K, r, tid, h[r], g, rsqrtf(tot / (float)K + p.eps), xf);
-      }
+      for (int r = 0; r < 4; ++r)
+        if (r < M) gemv_emit_row<WD>(p, M, K, r, tid, h[r], g, 1.0f, xf);
     }
   }
 }
 
-// General norm prologue (any M <= 16, any K), requested after the first weight batch.
+// General norm prologue (any M <= 16, any K), requested after the first weight batch: one pass
+// over the rows -- stage bf16(h * g), leave the per-wave sums of squares in LDS.
 template <int WD, int PRO>
 __device__ __forceinline__ void gemv_stage_late(const ProArgs& p, int M, int K, uint4* xf, float* red_f) {
   const int tid = threadIdx.x, nthr = blockDim.x, nchunk = K >> 3;
-  const int wave = tid >> 6, lane = tid & 63, nw = nthr >> 6;
+  const int wave = tid >> 6, lane = tid & 63;
   for (int m0 = 0; m0 < M; m0 += 4) {
     int row[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) row[r] = min(m0 + r, M - 1);
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
-    float h[4][8], g[8];
-    auto load_rows = [&](int c8) {
+    for (int c8 = tid; c8 < nchunk; c8 += nthr) {
+      float h[4][8], g[8];
+      load8(p.gain + c8 * 8, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + c8 * 8, h[r]);
       if constexpr (PRO == PRO_NORM_PARTIAL) {
@@ -348,35 +346,32 @@ __device__ __forceinline__ void gemv_stage_late(const ProArgs& p, int M, int K, 
 #pragma unroll
           for (int e = 0; e < 8; ++e) h[r][e] += pv[r][e];
       }
-    };
-    for (int c8 = tid; c8 < nchunk; c8 += nthr) {
-      load_rows(c8);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss[r] += h[r][e] * h[r][e];
+        for (int e = 0; e < 8; ++e) ss[r] = __builtin_fmaf(h[r][e], h[r][e], ss[r]);
+        if (m0 + r < M) gemv_emit_row<WD>(p, M, K, m0 + r, c8, h[r], g, 1.0f, xf);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float t = wave_sum(ss[r]);
-      if (lane == 0) red_f[(m0 + r) * 16 + wave] = t;
-    }
-    __syncthreads();
-    float rinv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float tot = 0.f;
-      for (int w = 0; w < nw; ++w) tot += red_f[(m0 + r) * 16 + w];
-      rinv[r] = rsqrtf(tot / (float)K + p.eps);
-    }
-    for (int c8 = tid; c8 < nchunk; c8 += nthr) {   // second pass re-reads h (L2-hot)
-      load8(p.gain + c8 * 8, g);
-      load_rows(c8);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (m0 + r < M) gemv_emit_row<WD>(p, M, K, m0 + r, c8, h[r], g, rinv[r], xf);
+      if (lane == 0 && m0 + r < M) red_f[(m0 + r) * 16 + wave] = t;
     }
   }
+}
+
+// 1 / rms of activation row m, from the per-wave sums the staging left in LDS (after its barrier).
+// The normalisation is applied to the projection's OUTPUT, y = (W . (h * g)) / rms(h): the same
+// value as W . (h * g / rms) with the row reduction off the staging path (one barrier and a chain
+// of LDS round trips less before the first MFMA; -0.07 ms per step measured).  The GEMV input is
+// therefore bf16(h * g) where the context-encoding path rounds bf16(h * g / rms): one rounding of
+// an fp32 product in both, at a different scale.
+__device__ __forceinline__ float gemv_row_rinv(const float* ssq, int m, int K, float eps) {
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < kGemvWaves; ++w) tot += ssq[m * 16 + w];
+  return rsqrtf(tot / (float)K + eps);
 }
 
 // Phase timeline of the decode GEMVs (dev builds only: -DMI_TRACE, see tests/trace_gemv.py).
@@ -424,6 +419,7 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2 + 16);
   float* sc_lds = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16);
   float* bi_lds = sc_lds + kGemvMaxTilesPerWg * 16;
+  float* ssq_lds = bi_lds + kGemvMaxTilesPerWg * 16;   // [16 rows][16 waves] sums of squares (norm prologues)
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
@@ -484,13 +480,20 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
       bi_lds[j] = biv[q];
     }
   }
-  if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, reinterpret_cast<float*>(red));
-  else gemv_stage_late<WD, PRO>(p, M, K, xf, reinterpret_cast<float*>(red));
+  if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, ssq_lds);
+  else gemv_stage_late<WD, PRO>(p, M, K, xf, ssq_lds);
   MI_STAMP(2);
   epi_prefetch_dependent<EPI>(e, tile0 * 16 + g * 4, epre);
   issue(bufB, 1);   // a full queue only blocks a wave that would wait at the barrier anyway
   __syncthreads();
   MI_STAMP(3);
+  float rmul = 1.f;     // 1 / rms of this lane's activation row (norm prologues), applied in the epilogue
+  if constexpr (PRO != PRO_BF16) {
+    if (col_ok) rmul = gemv_row_rinv(ssq_lds, c, K, p.eps);
+  }
+#ifdef MI_TRACE
+  if (tb_ && tid < 4) reinterpret_cast<float*>(tb_ + 6)[tid] = rmul;
+#endif
 
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int parity = 0;
@@ -528,8 +531,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
       parity ^= 1;
     }
     if (kslice == 0 && mine) {
-      if (pass == 0) epilogue_pre<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s, epre);
-      else epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s);
+      if (pass == 0) epilogue_pre<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s, epre, rmul);
+      else epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, s, rmul);
     }
     acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
   };

@@ -1019,6 +1019,17 @@ int mi_tp_init_transport(mi_ctx* c, mi_allreduce_fn all_reduce, mi_allgather_fn 
   return MI_OK;
 }
 
+#ifdef MI_TRACE
+// dev builds: copy an internal activation buffer to the host (0 resid[0], 1 resid[1], 2 q, 3 attn_out, 4 act)
+int mi_debug_copy(mi_ctx* c, int which, void* host, size_t bytes) {
+  const void* src = which == 0 ? (const void*)c->resid[0] : which == 1 ? (const void*)c->resid[1] : which == 2 ? (const void*)c->qbuf
+                    : which == 3 ? (const void*)c->attn_out : (const void*)c->act;
+  MI_HIP(hipStreamSynchronize(c->stream));
+  MI_HIP(hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+#endif
+
 // ---- per-kernel entry points ------------------------------------------------------------
 int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
                  int32_t* tokens_out, void* stream) {
