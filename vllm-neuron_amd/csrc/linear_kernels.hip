@@ -448,30 +448,44 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
     for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * kstep);
   };
 
-  // ---- prologue: own operands first, then the first weight batch, then consume (see above) ---
+  // ---- prologue.  A wave's vector loads RETIRE IN ORDER, so the request order is the wait order:
+  //   1. the activations (L2-resident: the previous launch has just written them) -- all the
+  //      staging arithmetic waits for;
+  //   2. the scales / biases / epilogue operands of this work-group -- first touched in this step,
+  //      so they come from HBM; requested behind the activations they no longer hold them up
+  //      (requested first they cost every launch an HBM round trip before staging: -2.5 % of the
+  //      decode step, measured), and they have landed by the time staging is done;
+  //   3. the first weight batch.
   const int nsc = my_units * TP * 16;   // scale / bias of local tile slot j = pass * TP + sub-tile
-  float scv[2], biv[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int j = min(tid + q * (int)blockDim.x, nsc - 1);
-    const int slot = j >> 4, r = j & 15;
-    const int tile = min((int)(blockIdx.x + (slot / TP) * gridDim.x) * TP + (slot % TP), NT - 1);
-    scv[q] = e.scale[tile * 16 + r];
-    biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
-  }
   u32x4_t pro_x[ProShape<PRO>::NX];
   float pro_h[ProShape<PRO>::NH][8], pro_p[ProShape<PRO>::NP][8], pro_g[8];
   const bool early = gemv_pro_is_early<PRO>(M, K);
   gemv_pro_load<PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g);   // unconditional (clamped); ignored on the late path
-  // epilogue operands of this work-group's first row-tile (clamped; used by the finishing lanes)
+  __builtin_amdgcn_sched_barrier(0);
+  // only the threads that own an entry ask for it (a work-group owns 16..512 scales)
+  float scv[2] = {0.f, 0.f}, biv[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = tid + q * (int)blockDim.x;
+    if (j < nsc) {
+      const int slot = j >> 4, r = j & 15;
+      const int tile = min((int)(blockIdx.x + (slot / TP) * gridDim.x) * TP + (slot % TP), NT - 1);
+      scv[q] = e.scale[tile * 16 + r];
+      biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
+    }
+  }
+  // epilogue operands of this work-group's first row-tile (used by the finishing lanes)
   const int tile0 = min((int)blockIdx.x * TP + min(tsub, TP - 1), NT - 1);
-  EpiPre<EPI> epre;
-  epi_prefetch<EPI>(e, min(c, M - 1), tile0 * 16 + g * 4, epre);
+  EpiPre<EPI> epre{};
+  const bool finisher = wave_on && kslice == 0;      // the waves that run this work-group's epilogues
+  if (finisher) epi_prefetch<EPI>(e, min(c, M - 1), tile0 * 16 + g * 4, epre);
   __builtin_amdgcn_sched_barrier(0);
   issue(bufA, 0);
   __builtin_amdgcn_sched_barrier(0);
   MI_STAMP(1);
   if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
+  if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, ssq_lds);
+  else gemv_stage_late<WD, PRO>(p, M, K, xf, ssq_lds);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int j = tid + q * (int)blockDim.x;
@@ -480,10 +494,8 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
       bi_lds[j] = biv[q];
     }
   }
-  if (early) gemv_pro_finish<WD, PRO>(p, M, K, pro_x, pro_h, pro_p, pro_g, xf, ssq_lds);
-  else gemv_stage_late<WD, PRO>(p, M, K, xf, ssq_lds);
   MI_STAMP(2);
-  epi_prefetch_dependent<EPI>(e, tile0 * 16 + g * 4, epre);
+  if (finisher) epi_prefetch_dependent<EPI>(e, tile0 * 16 + g * 4, epre);
   issue(bufB, 1);   // a full queue only blocks a wave that would wait at the barrier anyway
   __syncthreads();
   MI_STAMP(3);
