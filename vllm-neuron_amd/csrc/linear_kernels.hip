@@ -900,21 +900,27 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
         dst[i][t] = *reinterpret_cast<const u32x4_t*>(W + ((size_t)nt * KT + ks * 2 + t) * 64 + lane);
     }
   };
+  MI_TRACE_BEGIN();
+  MI_STAMP(0);
   if (ks_beg < nks) {
     load_x(ks_beg);
     load_w(wr, ks_beg);
   }
   for (int ks = ks_beg; ks < nks; ++ks) {
+    if (ks == ks_beg + 4) MI_STAMP(1);     // tests/trace_gemm.py: phases of the fifth K-step
+    if (ks == ks_beg + 5) MI_STAMP(6);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
       *reinterpret_cast<u32x4_t*>(&xs[row * kA8Pitch + ch * 16]) = xr[i];
     }
     __syncthreads();
+    if (ks == ks_beg + 4) MI_STAMP(2);
     if (ks + 1 < nks) {
       load_x(ks + 1);
       load_w(wn, ks + 1);
     }
+    if (ks == ks_beg + 4) MI_STAMP(3);
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const unsigned char* xrow = &xs[(mt * 16 + c) * kA8Pitch + g * 16];
@@ -928,7 +934,9 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
         acc[i][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i][mt], 0, 0, 0, kUnit, 0, kUnit);
       }
     }
+    if (ks == ks_beg + 4) MI_STAMP(4);
     __syncthreads();
+    if (ks == ks_beg + 4) MI_STAMP(5);
     if (ks + 1 < nks) {
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
@@ -953,6 +961,8 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
       }
     }
   }
+  MI_STAMP(7);
+  MI_TRACE_END();
 }
 
 template <int EPI>
