@@ -316,7 +316,7 @@ template <int HD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
     const uint16_t* __restrict__ q, int T, int q_pos0, const uint16_t* __restrict__ kpool,
     const uint16_t* __restrict__ vpool, int bs, const int32_t* __restrict__ block_table, int nh, int nkv, int G,
-    int Gp, uint16_t* __restrict__ out, float scale_log2e) {
+    int Gp, int paired, uint16_t* __restrict__ out, float scale_log2e) {
   constexpr int KP = HD + 8;    // row pitch (elements): +16 B keeps ds_read_b128 / tr reads off one bank window
   constexpr int CPR = HD / 8;   // 16-byte chunks per row
   constexpr int DN = HD / 16, KS = HD / 32;
@@ -336,11 +336,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
   const int kv_len = q_pos0 + T;
   for (int i = threadIdx.x; i < ceil_div(kv_len, bs); i += nthr) bt_lds[i] = block_table[i];
 
-  // Causal work grows linearly with the query block index, so a work-group takes block x and
-  // then its complement (nblk - 1 - x): every work-group does the same number of key tiles.
+  // Causal work grows linearly with the query block index.  paired (long prompts): a work-group
+  // takes block x and then its complement (nblk - 1 - x), every work-group the same number of key
+  // tiles, one work-group per CU.  Otherwise one block per work-group, heaviest first: two
+  // work-groups share a CU (a wave's softmax arithmetic runs under the other's MFMAs) and the
+  // dispatcher hands out the light blocks as the heavy ones finish.  (Measured on Llama-8B shapes:
+  // unpaired wins 1-3 % of the whole prefill up to the 1024 bucket, pairing wins 9 % at 2048.)
   const int nblk = ceil_div(T, 32 * QB);
-  for (int pass = 0; pass < 2; ++pass) {
-  const int xb = pass == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+  for (int pass = 0; pass < (paired ? 2 : 1); ++pass) {
+  const int xb = !paired ? nblk - 1 - (int)blockIdx.x : (pass == 0 ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x);
   if (pass == 1 && xb <= (int)blockIdx.x) break;   // odd count: the middle block is done once
   const int wg_q0 = xb * 32 * QB;
   const int q0 = wg_q0 + 32 * qb;            // this wave's 32 queries
@@ -551,8 +555,10 @@ int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kp
   const int Gp = G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8));
   const int waves = Gp < 4 ? 4 : Gp, QB = waves / Gp;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-  const dim3 grid(ceil_div(ceil_div(T, 32 * QB), 2), nkv);   // complementary query blocks are paired
-#define MI_PF(HD_, W_) hipLaunchKernelGGL((attn_prefill_kernel<HD_, W_>), grid, dim3(W_ * 64), 0, s, q, T, q_pos0, kpool, vpool, block_size, block_table, nh, nkv, G, Gp, out, scale_log2e)
+  const int nqb = ceil_div(T, 32 * QB);
+  const int paired = nqb * nkv > 384 ? 1 : 0;   // more blocks than 1.5 per CU: pair complementary ones
+  const dim3 grid(paired ? ceil_div(nqb, 2) : nqb, nkv);
+#define MI_PF(HD_, W_) hipLaunchKernelGGL((attn_prefill_kernel<HD_, W_>), grid, dim3(W_ * 64), 0, s, q, T, q_pos0, kpool, vpool, block_size, block_table, nh, nkv, G, Gp, paired, out, scale_log2e)
   if (hd == 128) { if (waves == 4) MI_PF(128, 4); else MI_PF(128, 8); }
   else { if (waves == 4) MI_PF(64, 4); else MI_PF(64, 8); }
 #undef MI_PF
