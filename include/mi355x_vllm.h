@@ -84,7 +84,7 @@ typedef struct mi_model_config {
 } mi_model_config;
 
 const char* mi_last_error(void);
-int mi_version(void);
+int mi_version(void);   /* 2 = this header; 1 lacked mi_forward_tokens, mi_op_sample, mi_tp_init_transport */
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out);
 int mi_ctx_destroy(mi_ctx* ctx);

@@ -559,7 +559,7 @@ int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
 extern "C" {
 
 const char* mi_last_error(void) { return mi::g_err.c_str(); }
-int mi_version(void) { return 1; }
+int mi_version(void) { return 2; }   // 2: + mi_forward_tokens, mi_op_sample, mi_tp_init_transport (additions only)
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   MI_CHECK(cfg && out, "null argument");
