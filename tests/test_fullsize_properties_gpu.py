@@ -1,7 +1,15 @@
-"""Parity at BASELINE.json's full size (Llama-3.1-8B shapes: 32 layers, H 4096, 32/8 heads x 128,
-I 14336, V 128256, FP8 per-channel weights, block_size 32, max_num_seqs 4, max_model_len 2048),
-where the CPU oracle would take hours: size-independent properties of the call contract that hold
-for ANY weights, checked on seeded synthetic weights generated on the device.
+"""Parity at BASELINE.json's full sizes, where the CPU oracle would take hours: size-independent
+properties of the call contract that hold for ANY weights, checked on seeded synthetic weights
+generated on the device.  One model per BASELINE config that fits one GPU:
+
+  config 3 (headline)  Llama-3.1-8B   32 layers, H 4096, 32/8 heads x 128, I 14336, V 128256, FP8 per-channel
+  config 2             Llama-3.1-8B   the same shapes, bf16 weights
+  config 4             Qwen2.5-7B     28 layers, H 3584, 28/4 heads x 128, I 18944, V 152064, INT8 per-channel,
+                                      qkv bias, prefix caching with a 512-token shared prefix;
+                                      down_proj (K = 18944) runs the K-chunked GEMV
+  (config 5, Llama-3.3-70B at TP 8, is in tests/test_tp_group_gpu.py)
+
+all at block_size 32, max_num_seqs 4, max_model_len 2048, pa_num_blocks 4096 (+ the null block).
 
   exact (bit-for-bit)
     * a model call does not depend on WHICH physical blocks hold the context (block permutation);
@@ -38,14 +46,23 @@ def _close(a, b):
     return d.abs().max().item() <= TOL_MAX and d.pow(2).mean().sqrt().item() <= TOL_RMS
 
 
-def _model(a8=0, use_graphs=1):
+LLAMA31_8B = dict(num_layers=32, hidden_size=4096, num_heads=32, num_kv_heads=8, head_dim=128,
+                  intermediate_size=14336, vocab_size=128256, rms_norm_eps=1e-5, rope_theta=500000.0,
+                  rope_type=1, rope_factor=8.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0,
+                  rope_original_max_position=8192, qkv_bias=0, tie_word_embeddings=0)
+QWEN25_7B = dict(num_layers=28, hidden_size=3584, num_heads=28, num_kv_heads=4, head_dim=128,
+                 intermediate_size=18944, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                 rope_type=0, rope_factor=1.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0,
+                 rope_original_max_position=0, qkv_bias=1, tie_word_embeddings=0)
+CONFIGS = {"llama31_8b_fp8": (LLAMA31_8B, "f8e4m3"), "llama31_8b_bf16": (LLAMA31_8B, "bf16"),
+           "qwen25_7b_int8": (QWEN25_7B, "int8")}
+
+
+def _model(name="llama31_8b_fp8", a8=0, use_graphs=1):
     from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
-    m = NativeModel(num_layers=32, hidden_size=4096, num_heads=32, num_kv_heads=8, head_dim=128,
-                    intermediate_size=14336, vocab_size=128256, rms_norm_eps=1e-5, rope_theta=500000.0,
-                    rope_type=1, rope_factor=8.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0,
-                    rope_original_max_position=8192, qkv_bias=0, tie_word_embeddings=0,
-                    num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
-                    weight_dtype=MI_W["f8e4m3"], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
+    geo, wd = CONFIGS[name]
+    m = NativeModel(**geo, num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
+                    weight_dtype=MI_W[wd], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
                     tp_degree=1, tp_rank=0, device_id=0, use_graphs=use_graphs, ctx_buckets=[256, 512, 1024, 2048],
                     prefill_fp8_activations=a8)
     m.init_synthetic_weights(1, 0.02)
@@ -53,9 +70,10 @@ def _model(a8=0, use_graphs=1):
     return m
 
 
-@pytest.fixture(scope="module")
-def model():
-    m = _model()
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def model(request):
+    m = _model(request.param)
+    m.vocab = CONFIGS[request.param][0]["vocab_size"]
     yield m
     m.close()
 
@@ -64,12 +82,12 @@ def _blocks(seed, n=MB):
     return (torch.randperm(NB - 1, generator=torch.Generator().manual_seed(seed)) + 1)[:n].tolist()
 
 
-def _prompt(n, seed=0):
-    return torch.randint(0, 128256, (n,), generator=torch.Generator().manual_seed(seed)).tolist()
+def _prompt(n, seed=0, vocab=128256):
+    return torch.randint(0, vocab, (n,), generator=torch.Generator().manual_seed(seed)).tolist()
 
 
 def test_block_permutation_invariance_and_idempotence(model):
-    p = _prompt(700)
+    p = _prompt(700, vocab=model.vocab)
     a = model.forward(**prefill_inputs(p, _blocks(1), BS, MAXLEN, 0))
     b = model.forward(**prefill_inputs(p, _blocks(2), BS, MAXLEN, 0))
     c = model.forward(**prefill_inputs(p, _blocks(2), BS, MAXLEN, 0))
@@ -79,7 +97,7 @@ def test_block_permutation_invariance_and_idempotence(model):
 
 def test_teacher_forcing_encoding_equals_generation(model):
     for n in (300, 1025):
-        p = _prompt(n, seed=n)
+        p = _prompt(n, seed=n, vocab=model.vocab)
         blocks = _blocks(3)
         full = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))           # logits at position n-1
         model.forward(**prefill_inputs(p[:-1], blocks, BS, MAXLEN, 0))             # KV for 0..n-2
@@ -89,7 +107,7 @@ def test_teacher_forcing_encoding_equals_generation(model):
 
 
 def test_prefix_cache_hit_equals_full_encoding(model):
-    p = _prompt(900, seed=5)
+    p = _prompt(900, seed=5, vocab=model.vocab)
     blocks = _blocks(4)
     full = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 0))
     hit = model.forward(**prefill_inputs(p, blocks, BS, MAXLEN, 256))              # blocks 0..7 already hold the prefix
@@ -98,7 +116,7 @@ def test_prefix_cache_hit_equals_full_encoding(model):
 
 def test_batch_rows_are_independent_and_graph_replay_is_exact(model):
     n = 513
-    p = _prompt(n, seed=9)
+    p = _prompt(n, seed=9, vocab=model.vocab)
     perm = _blocks(10, NSEQ * MB)                   # disjoint physical blocks per row
     rows = [perm[i * MB:(i + 1) * MB] for i in range(NSEQ)]
     for blocks in rows:
@@ -112,6 +130,32 @@ def test_batch_rows_are_independent_and_graph_replay_is_exact(model):
     one = model.forward(**decode_inputs([p[-1]], [n - 1], [rows[2]], BS, MAXLEN))
     assert _close(one[0], first[2])                 # B = 1 splits the context differently: same value, other summation order
     assert model.forward_tokens(**inp4).tolist() == first.argmax(dim=1).tolist()
+
+
+def test_shared_prefix_batch_matches_unshared(model):
+    """four sequences sharing a 512-token prefix (16 full blocks, the SAME
+    physical blocks in every block table) + unique suffixes of 64..256 tokens.  Encoding each
+    suffix on top of the cached prefix (computed_context_lens = 512) must equal encoding the whole
+    prompt into private blocks, and so must the following token-generation batch."""
+    prefix = _prompt(512, seed=21, vocab=model.vocab)
+    sufs = [_prompt(n, seed=30 + i, vocab=model.vocab) for i, n in enumerate((64, 128, 200, 256))]
+    perm = _blocks(22, 9 * MB)                      # disjoint: 16 shared blocks, 4 suffix tails, 4 private rows
+    shared = perm[:16]
+    hit_rows = [shared + perm[(1 + i) * MB:(1 + i) * MB + MB - 16] for i in range(NSEQ)]
+    own_rows = [perm[(5 + i) * MB:(6 + i) * MB] for i in range(NSEQ)]
+    hit_logits, own_logits = [], []
+    model.forward(**prefill_inputs(prefix, shared, BS, MAXLEN, 0))                        # the prefix's KV
+    for i, suf in enumerate(sufs):
+        hit_logits.append(model.forward(**prefill_inputs(prefix + suf, hit_rows[i], BS, MAXLEN, 512)))
+    toks = [int(l.argmax()) for l in hit_logits]
+    pos = [512 + len(sf) for sf in sufs]
+    step_hit = model.forward(**decode_inputs(toks, pos, hit_rows, BS, MAXLEN))
+    for i, suf in enumerate(sufs):
+        own_logits.append(model.forward(**prefill_inputs(prefix + suf, own_rows[i], BS, MAXLEN, 0)))
+    step_own = model.forward(**decode_inputs(toks, pos, own_rows, BS, MAXLEN))
+    for i in range(NSEQ):
+        assert _close(hit_logits[i], own_logits[i]), i
+    assert _close(step_hit, step_own)
 
 
 def test_fp8_activation_mode_is_the_same_function_up_to_its_quantization_noise():

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
       L += f * sm_ml[(w * 16 + h) * 2 + 1];
     }
     if constexpr (FINAL) {
-      out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(o / L);
+      out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(L > 0.f ? o / L : 0.f);   // empty context -> zeros
     } else {
       const size_t row = ((size_t)b * nh + kvh * G + h) * NS + split;
       o_part[row * HD + d] = o;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(HD) void attn_combine_kernel(const float* __restric
     acc += f * ov[s];
     L += f * lv[s];
   }
-  out[((size_t)b * nh + head) * HD + d] = f32_to_bf16(acc / L);
+  out[((size_t)b * nh + head) * HD + d] = f32_to_bf16(L > 0.f ? acc / L : 0.f);   // empty context -> zeros
 }
 
 int attn_decode_splits(int B, int nkv) {
@@ -263,13 +263,10 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
   float* ml_part = o_part + (size_t)B * nh * kAttnMaxSplits * HD;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
   constexpr size_t lds8 = attn_decode_lds<HD, 8>(), lds4 = attn_decode_lds<HD, 4>();
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<HD, 8, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<HD, 4, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
-    attr_set = true;
+  {
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(attn_decode_kernel<HD, 8, true>), (int)lds8);
+    if (rc == MI_OK) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(attn_decode_kernel<HD, 4, false>), (int)lds4);
+    if (rc != MI_OK) return rc;
   }
   if (NS == 1) {
     // Enough (sequence, kv head) pairs to fill the chip: one launch, no partials.  (Measured: a

@@ -28,6 +28,12 @@
 
 namespace mi {
 
+#define MI_TRY_(expr)              \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != MI_OK) return _rc;  \
+  } while (0)
+
 // =====================================================================================
 // Epilogue
 // =====================================================================================
@@ -188,7 +194,10 @@ size_t gemv_lds_bytes(int M, int K) {
   // x image, zero slot, reduction buffers, scale + bias cache, per-wave sums of squares [16 rows][16]
   return (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16 + 2 * kGemvMaxTilesPerWg * 16 * 4 + 16 * 16 * 4;
 }
-bool gemv_fits(int M, int K) { return M <= 16 && gemv_lds_bytes(M, K) <= 160 * 1024; }
+// every M <= 16 streams the weights: images that do not fit in LDS whole are staged in K-chunks
+// (gemv_bigk_kernel)
+bool gemv_fits(int M, int K) { (void)K; return M <= 16; }
+static bool gemv_fits_whole(int M, int K) { return gemv_lds_bytes(M, K) <= 160 * 1024; }
 
 // position (in 16-byte units) of the 8-element chunk c8 of row m in the fragment image
 template <int WD>
@@ -595,11 +604,7 @@ static int launch_gemv_ks(const LinearW& w, int M, int TP, const ProArgs& p, con
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
   const size_t lds = gemv_lds_bytes(M, w.K);
   auto kern = gemv_kernel<WD, PRO, EPI, KS>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
   // the grid is one resident wave of work-groups (one per CU: ~200 VGPRs x 8 waves), each walking
   // its share of the row-tiles
   const int units = ceil_div(NT, TP);
@@ -613,13 +618,13 @@ static int launch_gemv_ks(const LinearW& w, int M, int TP, const ProArgs& p, con
 }
 
 template <int WD, int PRO, int EPI>
+static int launch_gemv_bigk_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s);
+
+template <int WD, int PRO, int EPI>
 static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    MI_HIP(hipGetDevice(&dev));
-    MI_HIP(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  if (!gemv_fits_whole(M, w.K)) return launch_gemv_bigk_t<WD, PRO, EPI>(w, M, p, e, s);
+  int num_cu = 0;
+  MI_TRY_(device_num_cu(&num_cu));
   const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
   switch (sh.ks) {
     case 1: return launch_gemv_ks<WD, PRO, EPI, 1>(w, M, sh.tp, p, e, s, num_cu);
@@ -627,6 +632,217 @@ static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArg
     case 4: return launch_gemv_ks<WD, PRO, EPI, 4>(w, M, sh.tp, p, e, s, num_cu);
     default: return launch_gemv_ks<WD, PRO, EPI, 8>(w, M, sh.tp, p, e, s, num_cu);
   }
+}
+
+
+// =====================================================================================
+// GEMV with the activations staged in K-chunks (images larger than the LDS)
+// =====================================================================================
+// down_proj of Qwen2.5-7B (K = 18944) and of Llama-3.3-70B (K = 28672 at TP 1, 14336 at TP 2), or
+// any projection at M > 8 rows of an 8192-wide model: M x K bf16 does not fit beside the reduction
+// buffers.  Same arithmetic as gemv_kernel (bf16 activations in MFMA-fragment order, fp32
+// accumulation, dequant / norm scale in the epilogue), other schedule: one work-group = 8 waves
+// owns ONE row-tile at a time, its waves split every K-chunk eight ways, the chunk's activations
+// are staged between two barriers while the next chunk's first weight batches are already in
+// flight.  The K-slices are combined in wave order (deterministic).
+// LDS: [x chunk: CKT k-tiles][zero slot][red: 8 waves x 64 lanes x 16 B][scale 16][bias 16][ssq 16 x 16]
+static size_t gemv_bigk_fixed_lds() { return 16 + kGemvWaves * 64 * 16 + 2 * 16 * 4 + 16 * 16 * 4; }
+static int gemv_bigk_chunk_kt(int M, int K, int wd) {
+  const int KT = K / tile_k(wd);
+  const size_t per_kt = (size_t)M * tile_k(wd) * 2;
+  const int cap = (int)((160 * 1024 - gemv_bigk_fixed_lds()) / per_kt);
+  const int NC = ceil_div(KT, cap);
+  return min(cap, ceil_div(ceil_div(KT, NC), kGemvWaves) * kGemvWaves);   // equal slices for the 8 waves
+}
+
+// stage x[:, k0 .. k0 + ck) (ck elements, a multiple of the k-tile) into the fragment image; norm
+// prologues leave / accumulate the per-wave sums of squares in ssq[row * 16 + wave]
+template <int WD, int PRO>
+__device__ __forceinline__ void gemv_stage_chunk(const ProArgs& p, int M, int K, int k0, int ck, uint4* xf, float* ssq,
+                                                 bool first_chunk, bool take_ssq, bool store_resid) {
+  const int tid = threadIdx.x, nthr = blockDim.x, nch = ck >> 3, c0 = k0 >> 3;
+  if constexpr (PRO == PRO_BF16) {
+    const int total = M * nch;
+    for (int i = tid; i < total; i += nthr) {
+      const int m = i / nch, c8 = i - m * nch;
+      xf[xfrag_slot<WD>(c8, m, M)] = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + (size_t)(c0 + c8) * 8);
+    }
+  } else {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int m0 = 0; m0 < M; m0 += 4) {
+      int row[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) row[r] = min(m0 + r, M - 1);
+      float ss[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c8 = tid; c8 < nch; c8 += nthr) {
+        float h[4][8], g[8];
+        load8(p.gain + (size_t)(c0 + c8) * 8, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) load8(p.resid_in + (size_t)row[r] * K + (size_t)(c0 + c8) * 8, h[r]);
+        if constexpr (PRO == PRO_NORM_PARTIAL) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv[8];
+            load8(p.partial + (size_t)row[r] * K + (size_t)(c0 + c8) * 8, pv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[r][e] += pv[e];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss[r] = __builtin_fmaf(h[r][e], h[r][e], ss[r]);
+          if (m0 + r < M) {
+            if (store_resid && p.resid_out) {
+              float* o = p.resid_out + (size_t)(m0 + r) * K + (size_t)(c0 + c8) * 8;
+              *reinterpret_cast<float4*>(o) = make_float4(h[r][0], h[r][1], h[r][2], h[r][3]);
+              *reinterpret_cast<float4*>(o + 4) = make_float4(h[r][4], h[r][5], h[r][6], h[r][7]);
+            }
+            uint4 o4;
+            o4.x = pack_bf16x2(h[r][0] * g[0], h[r][1] * g[1]);
+            o4.y = pack_bf16x2(h[r][2] * g[2], h[r][3] * g[3]);
+            o4.z = pack_bf16x2(h[r][4] * g[4], h[r][5] * g[5]);
+            o4.w = pack_bf16x2(h[r][6] * g[6], h[r][7] * g[7]);
+            xf[xfrag_slot<WD>(c8, m0 + r, M)] = o4;
+          }
+        }
+      }
+      if (take_ssq) {   // the sums belong to the activations, not to the row-tile: taken once
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = wave_sum(ss[r]);
+          if (lane == 0 && m0 + r < M) ssq[(m0 + r) * 16 + wave] = first_chunk ? t : ssq[(m0 + r) * 16 + wave] + t;
+        }
+      }
+    }
+  }
+}
+
+template <int WD, int PRO, int EPI>
+__global__ __launch_bounds__(kGemvWaves * 64) void gemv_bigk_kernel(const uint4* __restrict__ W, int NT, int KT, int M,
+                                                                    int K, int CKT, ProArgs p, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TK = (WD == MI_W_BF16) ? 32 : 64;
+  uint4* xf = reinterpret_cast<uint4*>(smem);
+  const int zero_slot = (M * CKT * TK) >> 3;
+  unsigned char* tail = smem + (size_t)M * CKT * TK * 2 + 16;
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);
+  float* sc_lds = reinterpret_cast<float*>(tail + kGemvWaves * 64 * 16);
+  float* bi_lds = sc_lds + 16;
+  float* ssq_lds = bi_lds + 16;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const bool col_ok = c < M;
+  const int NC = ceil_div(KT, CKT);
+  const int ktw = ceil_div(CKT, kGemvWaves);          // k-tiles of a chunk per wave
+  const int nb = ceil_div(ktw, kGemvU);               // batches per (tile, chunk), same for every wave
+  const int my_tiles = (int)blockIdx.x < NT ? ceil_div(NT - (int)blockIdx.x, (int)gridDim.x) : 0;
+  const int total = my_tiles * NC * nb;
+
+  // sequence index -> (tile, chunk, batch); the slice of wave w inside chunk ch is
+  // [ch * CKT + w * ktw, ... + ktw) clipped to the chunk and to KT
+  auto slice = [&](int ch, int& kbeg, int& kend) {
+    const int cend = min((ch + 1) * CKT, KT);
+    kbeg = min(ch * CKT + wave * ktw, cend);
+    kend = min(kbeg + ktw, cend);
+  };
+  u32x4_t bufA[kGemvU], bufB[kGemvU];
+  auto issue = [&](u32x4_t (&buf)[kGemvU], int i) {
+    const bool live = i < total;
+    i = min(i, max(total - 1, 0));
+    const int it = i / (NC * nb), rem = i - it * NC * nb, ch = rem / nb, b = rem - ch * nb;
+    int kbeg, kend;
+    slice(ch, kbeg, kend);
+    const int tile = min((int)blockIdx.x + it * (int)gridDim.x, NT - 1);
+    const int klast = max(kend - 1, kbeg);
+    const bool any = live && kbeg < kend;
+    const uint4* base = any ? W + (size_t)tile * KT * 64 + lane : W;
+    const size_t kstep = any ? 64 : 0;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kbeg + b * kGemvU + u, min(klast, KT - 1)) * kstep);
+  };
+
+  if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
+  issue(bufA, 0);
+  issue(bufB, 1);
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  auto process = [&](u32x4_t (&buf)[kGemvU], int i) {
+    const int it = i / (NC * nb), rem = i - it * NC * nb, ch = rem / nb, b = rem - ch * nb;
+    int kbeg, kend;
+    slice(ch, kbeg, kend);
+    if (b == 0) {   // a new chunk: every wave is done with the previous image
+      __syncthreads();
+      if (ch == 0 && tid < 16) {
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+        sc_lds[tid] = e.scale[tile * 16 + tid];
+        bi_lds[tid] = e.bias ? e.bias[tile * 16 + tid] : 0.f;
+      }
+      const int k0 = ch * CKT * TK, ck = (min((ch + 1) * CKT, KT) - ch * CKT) * TK;
+      gemv_stage_chunk<WD, PRO>(p, M, K, k0, ck, xf, ssq_lds, ch == 0, it == 0, it == 0 && blockIdx.x == 0);
+      __syncthreads();
+    }
+    const int kl0 = kbeg - ch * CKT + b * kGemvU;     // k-tile index inside the chunk image
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) {
+      const int kt = kl0 + u;
+      const bool ok = col_ok && (ch * CKT + kt) < kend;
+      const u32x4_t w = buf[u];
+      if constexpr (WD == MI_W_BF16) {
+        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, xf[ok ? (kt * 4 + g) * M + c : zero_slot]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), bb, acc, 0, 0, 0);
+      } else {
+        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 0) * 4 + g) * M + c : zero_slot]);
+        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 1) * 4 + g) * M + c : zero_slot]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
+      }
+    }
+    if (ch == NC - 1 && b == nb - 1) {   // row-tile done: combine the K-slices in wave order
+      red[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0 && col_ok) {
+        f32x4_t s = red[lane];
+#pragma unroll
+        for (int w = 1; w < kGemvWaves; ++w) {
+          const f32x4_t t = red[w * 64 + lane];
+          s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        float rmul = 1.f;
+        if constexpr (PRO != PRO_BF16) rmul = gemv_row_rinv(ssq_lds, c, K, p.eps);
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+        epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc_lds + g * 4, e.bias ? bi_lds + g * 4 : nullptr, s, rmul);
+      }
+      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  for (int i = 0; i < total; i += 2) {
+    process(bufA, i);
+    issue(bufA, i + 2);
+    if (i + 1 < total) process(bufB, i + 1);
+    issue(bufB, i + 3);
+  }
+}
+
+template <int WD, int PRO, int EPI>
+static int launch_gemv_bigk_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  const int NT = w.N / 16, KT = w.K / tile_k(WD);
+  const int CKT = gemv_bigk_chunk_kt(M, w.K, WD);
+  const size_t lds = (size_t)M * CKT * tile_k(WD) * 2 + gemv_bigk_fixed_lds();
+  MI_CHECK(CKT >= kGemvWaves && lds <= 160 * 1024, "gemv: activation chunk does not fit in LDS");
+  auto kern = gemv_bigk_kernel<WD, PRO, EPI>;
+  MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
+  int num_cu = 0;
+  MI_TRY_(device_num_cu(&num_cu));
+  // one row-tile per work-group at a time; more row-tiles than CUs -> every work-group walks
+  // an equal share (a grid that divides NT evenly, at most 2 per CU in flight order)
+  int grid = NT;
+  if (NT > num_cu) grid = ceil_div(NT, ceil_div(NT, num_cu));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s, reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K,
+                     CKT, p, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
 }
 
 // valid (prologue, epilogue) pairs: bf16 activations feed the row-parallel projections
@@ -652,7 +868,6 @@ static int launch_gemv_wd(const LinearW& w, int M, int pro, const ProArgs& p, in
 int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
   MI_CHECK(M >= 1 && M <= 16, "gemv: M must be 1..16");
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemv: N % 16 == 0 and K % 64 == 0 required");
-  MI_CHECK(gemv_fits(M, w.K), "gemv: x does not fit in LDS");
   switch (w.wd) {
     case MI_W_BF16: return launch_gemv_wd<MI_W_BF16>(w, M, pro, p, epi, e, s);
     case MI_W_F8E4M3: return launch_gemv_wd<MI_W_F8E4M3>(w, M, pro, p, epi, e, s);

@@ -170,6 +170,12 @@ __device__ __forceinline__ void stream_wait(u32x4_t&) {}
 
 __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- per-device launch state ------------------------------------------------------------
+// One process may drive several GPUs (the in-process tensor-parallel group): kernel attributes
+// and the CU count belong to the CURRENT device, never to the process.
+int device_num_cu(int* out);                                  // CUs of the current device
+int ensure_dynamic_lds(const void* kernel, int bytes);        // hipFuncSetAttribute once per (device, kernel)
+
 // weight tile geometry: a tile is 16 rows x TILE_K(wd) columns = 1 KiB, lane l owns
 // row (l & 15), k-chunk (l >> 4) of 16 bytes.
 __host__ __device__ __forceinline__ int tile_k(int wd) { return wd == MI_W_BF16 ? 32 : 64; }

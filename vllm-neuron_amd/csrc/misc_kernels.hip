@@ -2,7 +2,38 @@
 // context-encoding pass, synthetic weight generation, fp32 -> bf16 copies.
 #include "misc_kernels.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace mi {
+
+// ---- per-device launch state (mi_common.h) ------------------------------------------------
+int device_num_cu(int* out) {
+  static int cu[64] = {0};
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  MI_CHECK(dev >= 0 && dev < 64, "device id out of range");
+  int v = __atomic_load_n(&cu[dev], __ATOMIC_RELAXED);
+  if (v == 0) {
+    MI_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    __atomic_store_n(&cu[dev], v, __ATOMIC_RELAXED);
+  }
+  *out = v;
+  return MI_OK;
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  MI_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, kernel})) return MI_OK;
+  MI_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+  return MI_OK;
+}
 
 // resid[t, :] = fp32(E[ids[t], :])            (reference K1)
 __global__ void embed_kernel(const int32_t* __restrict__ ids, const uint16_t* __restrict__ table, int H,

@@ -572,7 +572,9 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   MI_CHECK(k.intermediate_size % k.tp_degree == 0 && k.vocab_size % k.tp_degree == 0, "intermediate/vocab must divide by tp_degree");
   MI_CHECK(k.block_size > 0 && k.block_size % 32 == 0, "block_size must be a positive multiple of 32");
   MI_CHECK(k.num_blocks >= 2, "num_blocks must include the null block and at least one real block");
-  MI_CHECK(k.max_num_seqs >= 1 && k.max_num_seqs <= 16, "max_num_seqs must be 1..16");
+  // token-generation batches of up to 16 rows stream the weights (GEMV); larger ones take the
+  // context-encoding GEMMs (vLLM's default max_num_seqs for this platform is 32, platform.py)
+  MI_CHECK(k.max_num_seqs >= 1 && k.max_num_seqs <= 256, "max_num_seqs must be 1..256");
   MI_CHECK(k.max_model_len >= 1, "max_model_len");
   MI_CHECK(k.weight_dtype >= MI_W_BF16 && k.weight_dtype <= MI_W_INT8, "weight_dtype");
   MI_CHECK(k.quant_type == MI_Q_PER_TENSOR_SYMMETRIC || k.quant_type == MI_Q_PER_CHANNEL_SYMMETRIC, "quant_type");
@@ -688,6 +690,18 @@ int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
     MI_TRY(gen(nm("mlp.gate_proj.weight"), k.intermediate_size, c->H, std));
     MI_TRY(gen(nm("mlp.up_proj.weight"), k.intermediate_size, c->H, std));
     MI_TRY(gen(nm("mlp.down_proj.weight"), c->H, k.intermediate_size, std));
+    if (k.qkv_bias) {   // Qwen2: FULL bias vectors in logical coordinates, each rank routes its slice
+      const char* bn[3] = {"self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias"};
+      for (int i = 0; i < 3; ++i) {
+        const int n = (i == 0 ? k.num_heads : k.num_kv_heads) * c->hd;
+        MI_TRY(ensure_stage(c, (size_t)n, n));
+        MI_TRY(launch_randn(c->stage_f32, (size_t)n, seed, tid++, 0.25f, c->stream));
+        std::vector<float> hb((size_t)n);
+        MI_HIP(hipMemcpyAsync(hb.data(), c->stage_f32, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        MI_HIP(hipStreamSynchronize(c->stream));
+        MI_TRY(route_vector(c, nm(bn[i]), hb));
+      }
+    }
     MI_TRY(launch_fill_f32(c->layers[l].g_in, c->H, 1.0f, c->stream));
     MI_TRY(launch_fill_f32(c->layers[l].g_post, c->H, 1.0f, c->stream));
   }
