@@ -46,12 +46,23 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // consumed); a tile past the wave's range is requested as one harmless line of the null block, so
 // the loop has no predicated loads.  Rows of the last tile beyond the context are masked by score;
 // the pool must not hold NaN/Inf there (the library zero-fills it and only ever writes finite values).
-template <int HD, int NW, bool FINAL>
+//
+// MERGE (with !FINAL): the context splits of one (sequence, kv head) are merged by whichever of
+// their NS work-groups finishes LAST, inside this launch -- no combine launch.  No work-group ever
+// waits for another (nothing can hang): each publishes its partial with write-through (sc1) stores,
+// every storing wave drains them, one lane takes a ticket from an agent-scope counter, and the
+// work-group whose ticket is NS - 1 reads all NS partials back with sc1 loads (past its L1; no
+// other reader of these lines exists in the launch, so no L2 holds a stale copy) and writes the
+// bf16 output.  This is the hand-off form MI355X_MICROARCH.md lists as valid without fences
+// ("the workgroup whose add came last, told by the value its add returned"; one work-group per
+// CU: the launch pads its LDS request to keep it so).  The merge itself runs in split order, so the
+// result does not depend on which work-group performs it.  The counter is left at 0 for the next launch.
+template <int HD, int NW, bool FINAL, bool MERGE = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpool, const uint16_t* __restrict__ vpool,
     int bs, const int32_t* __restrict__ block_table, int MB, const int32_t* __restrict__ ctx_lens,
     int nh, int nkv, int G, int NS, float* __restrict__ o_part, float* __restrict__ ml_part,
-    uint16_t* __restrict__ out, float scale_log2e) {
+    uint16_t* __restrict__ out, float scale_log2e, unsigned int* __restrict__ tickets = nullptr) {
   constexpr int KP = HD + 8;        // LDS row pitch (elements)
   constexpr int CPR = HD / 8;       // 16-byte chunks per row
   constexpr int KS = HD / 32, DN = HD / 16;
@@ -203,12 +214,57 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     }
     if constexpr (FINAL) {
       out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(L > 0.f ? o / L : 0.f);   // empty context -> zeros
+    } else if constexpr (MERGE) {
+      const size_t row = ((size_t)b * nh + kvh * G + h) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
+      __hip_atomic_store(&o_part[row * HD + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store ... sc1
+      if (d == 0) {
+        __hip_atomic_store(&ml_part[row * 2], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ml_part[row * 2 + 1], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else {
-      const size_t row = ((size_t)b * nh + kvh * G + h) * NS + split;
+      const size_t row = ((size_t)b * nh + kvh * G + h) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
       o_part[row * HD + d] = o;
       if (d == 0) {
         ml_part[row * 2] = M;
         ml_part[row * 2 + 1] = L;
+      }
+    }
+  }
+  if constexpr (MERGE && !FINAL) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its write-through stores
+    __syncthreads();
+    int* s_last = reinterpret_cast<int*>(sm_ml);        // the m/l staging is dead behind the barrier
+    if (tid == 0) {
+      unsigned int* tk = tickets + (size_t)b * nkv + kvh;
+      const unsigned int t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = t == (unsigned int)(NS - 1);
+      if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      *s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (*s_last) {
+      for (int idx = tid; idx < G * HD; idx += NW * 64) {
+        const int h = idx / HD, d = idx % HD;
+        const size_t row0 = ((size_t)b * nh + kvh * G + h) * kAttnMaxSplits;
+        float mv[kAttnMaxSplits], lv[kAttnMaxSplits], ov[kAttnMaxSplits];
+#pragma unroll
+        for (int sp = 0; sp < kAttnMaxSplits; ++sp) {
+          const bool ok = sp < NS;
+          mv[sp] = ok ? __hip_atomic_load(&ml_part[(row0 + sp) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+          lv[sp] = ok ? __hip_atomic_load(&ml_part[(row0 + sp) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          ov[sp] = ok ? __hip_atomic_load(&o_part[(row0 + sp) * HD + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < kAttnMaxSplits; ++sp) M = fmaxf(M, mv[sp]);
+        float acc_o = 0.f, L = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < kAttnMaxSplits; ++sp) {   // split order: the same sums as attn_combine_kernel
+          const float f = sexp2(mv[sp], M);
+          acc_o += f * ov[sp];
+          L += f * lv[sp];
+        }
+        out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(L > 0.f ? acc_o / L : 0.f);
       }
     }
   }
@@ -223,7 +279,7 @@ template <int HD>
 __global__ __launch_bounds__(HD) void attn_combine_kernel(const float* __restrict__ o_part, const float* __restrict__ ml_part,
                                                           int NS, int nh, uint16_t* __restrict__ out) {
   const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-  const size_t row0 = ((size_t)b * nh + head) * NS;
+  const size_t row0 = ((size_t)b * nh + head) * kAttnMaxSplits;
   float mv[kAttnMaxSplits], lv[kAttnMaxSplits], ov[kAttnMaxSplits];
 #pragma unroll
   for (int s = 0; s < kAttnMaxSplits; ++s) {
@@ -250,22 +306,42 @@ int attn_decode_splits(int B, int nkv) {
   int ns = 256 / (B * nkv);  // ~one work-group per CU; >= 4 tiles (one per wave) each at 1k context
   return ns < 1 ? 1 : (ns > kAttnMaxSplits ? kAttnMaxSplits : ns);
 }
+// [tickets: kAttnTickets counters, one per (sequence, kv head), zero between launches]
+// [m/l partials: B x nh rows of one 128-byte line][o partials]  -- the ticket block and the m/l
+// rows sit at offsets that do not depend on the batch size of the call
+constexpr int kAttnTickets = 1024;
 size_t attn_scratch_bytes(int B, int nh, int hd) {
-  return (size_t)B * nh * kAttnMaxSplits * (hd + 2) * sizeof(float);
+  return kAttnTickets * sizeof(unsigned int) + (size_t)B * nh * kAttnMaxSplits * (hd + 2) * sizeof(float);
+}
+// Off by default: measured on Llama-3.1-8B decode (B 4, ctx 1024) the in-launch merge costs the
+// last work-group ~5.4 us (write-through drain + returning atomic + sc1 read-back are three
+// dependent trips to memory) against 4.8 us for the separate combine launch: 2.157 vs 2.138 ms per
+// step.  MI355X_ATTN_MERGE=1 selects it (same results: tests/test_model_gpu.py runs both).
+static bool attn_merge_enabled() {
+  static const bool on = [] { const char* v = getenv("MI355X_ATTN_MERGE"); return v && v[0] == '1'; }();
+  return on;
 }
 
 template <int HD>
 static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int bs,
                            const int32_t* bt, int MB, const int32_t* ctx, int B, int nh, int nkv,
-                           uint16_t* out, void* scratch, hipStream_t s) {
+                           uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed) {
   const int G = nh / nkv, NS = attn_decode_splits(B, nkv);
-  float* o_part = reinterpret_cast<float*>(scratch);
-  float* ml_part = o_part + (size_t)B * nh * kAttnMaxSplits * HD;
+  // in-launch merge: needs every split's work-group resident on a CU of its own (grid <= CUs) and
+  // the ticket counters at zero (the model keeps them so; the per-op entry cannot know)
+  int num_cu = 0;
+  if (device_num_cu(&num_cu) != MI_OK) return MI_EHIP;
+  const bool merge = attn_merge_enabled() && NS > 1 && tickets_zeroed && NS * nkv * B <= num_cu && nkv * B <= kAttnTickets;
+  unsigned int* tickets = reinterpret_cast<unsigned int*>(scratch);
+  float* ml_part = reinterpret_cast<float*>(tickets + kAttnTickets);
+  float* o_part = ml_part + (size_t)B * nh * kAttnMaxSplits * 2;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
   constexpr size_t lds8 = attn_decode_lds<HD, 8>(), lds4 = attn_decode_lds<HD, 4>();
+  constexpr size_t kMergeLds = 96 * 1024;   // more than half a CU's LDS: one work-group per CU (see the kernel comment)
   {
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(attn_decode_kernel<HD, 8, true>), (int)lds8);
     if (rc == MI_OK) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(attn_decode_kernel<HD, 4, false>), (int)lds4);
+    if (rc == MI_OK) rc = ensure_dynamic_lds(reinterpret_cast<const void*>(attn_decode_kernel<HD, 4, false, true>), (int)kMergeLds);
     if (rc != MI_OK) return rc;
   }
   if (NS == 1) {
@@ -274,10 +350,13 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
     // a short grid must split the context over CUs -- the one-launch form at B x nkv = 32 took
     // 16 us per 1k tokens of context against 8 + 5 us for split + combine.)
     hipLaunchKernelGGL((attn_decode_kernel<HD, 8, true>), dim3(1, nkv, B), dim3(512), lds8, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e);
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e, nullptr);
+  } else if (merge) {
+    hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false, true>), dim3(NS, nkv, B), dim3(256), kMergeLds, s, q,
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, out, scale_log2e, tickets);
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false>), dim3(NS, nkv, B), dim3(256), lds4, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e);
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e, nullptr);
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(nh, B), dim3(HD), 0, s, o_part, ml_part, NS, nh, out);
   }
   MI_HIP(hipGetLastError());
@@ -286,12 +365,12 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
 
 int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int block_size,
                        const int32_t* block_table, int MB, const int32_t* ctx_lens, int B, int nh,
-                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s) {
+                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
   MI_CHECK(nh % nkv == 0 && nh / nkv <= 16, "attention: q heads per kv head must be 1..16");
   MI_CHECK(block_size % 32 == 0, "attention: block_size must be a multiple of 32");
-  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s);
-  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s);
+  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
+  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
 }
 
 // =====================================================================================

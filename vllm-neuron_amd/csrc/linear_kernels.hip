@@ -576,6 +576,297 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kernel(const uint4* __re
   MI_TRACE_END();
 }
 
+
+// Kernel arguments are fetched on demand: hipcc places an s_load + s_waitcnt lgkmcnt(0) in front of
+// the first use of each piece, i.e. one scalar-cache miss (the kernarg block of a launch is cold)
+// per piece, back to back, on the way to the first weight request.  Naming every field as an SGPR
+// input of an empty asm at kernel entry makes the compiler fetch the whole block at once.
+template <typename T>
+__device__ __forceinline__ void pin_sgpr(const T& v) { asm volatile("" ::"s"(v)); }
+template <int PRO, int EPI>
+__device__ __forceinline__ void pin_gemv_args(const uint4* W, int NT, int KT, int M, int K, const ProArgs& p, const EpiArgs& e) {
+  pin_sgpr(W); pin_sgpr(NT); pin_sgpr(KT); pin_sgpr(M); pin_sgpr(K);
+  if constexpr (PRO == PRO_BF16) { pin_sgpr(p.x); pin_sgpr(p.ldx); }
+  else { pin_sgpr(p.resid_in); pin_sgpr(p.resid_out); pin_sgpr(p.gain); pin_sgpr(p.eps); }
+  if constexpr (PRO == PRO_NORM_PARTIAL) pin_sgpr(p.partial);
+  pin_sgpr(e.scale); pin_sgpr(e.bias);
+  if constexpr (EPI == EPI_F32 || EPI == EPI_RESID) { pin_sgpr(e.out_f32); pin_sgpr(e.ld_out); }
+  if constexpr (EPI == EPI_RESID) pin_sgpr(e.resid_in);
+  if constexpr (EPI == EPI_SWIGLU) { pin_sgpr(e.act_out); pin_sgpr(e.ld_act); }
+  if constexpr (EPI == EPI_QKV) {
+    pin_sgpr(e.q_out); pin_sgpr(e.q_dim); pin_sgpr(e.kv_dim); pin_sgpr(e.hd); pin_sgpr(e.nkv); pin_sgpr(e.pos);
+    pin_sgpr(e.slots); pin_sgpr(e.rope_cos); pin_sgpr(e.rope_sin); pin_sgpr(e.kpool); pin_sgpr(e.vpool);
+    pin_sgpr(e.block_size);
+  }
+}
+
+// =====================================================================================
+// GEMV, wave-private staging (the short K-split projections: QKV, O, down at M <= 4)
+// =====================================================================================
+// In-kernel timeline of gemv_kernel on the Llama-8B decode shapes (tests/trace_gemv.py, us, median
+// work-group): issue 1.2-1.7 | stage 2.0-2.9 | barrier 0.7-1.6 | first batch 1.0-1.5 | stream 1.0 (O)
+// ... 13.4 (gate|up).  For O-proj the 64 KiB a CU streams are 1 us of a 7 us kernel: the rest is the
+// serial chain kernel entry -> index arithmetic (runtime divisions) -> x from L2 -> LDS -> work-group
+// barrier -> first MFMA.  With K split over the waves (KS > 1) a wave multiplies only ITS K-slice
+// of the activations, so it stages exactly that slice, for itself, and never meets the other
+// waves before the K-slice reduction at the end of the row-tile:
+//   * no prologue barrier, a wave starts its MFMAs as soon as its own 1/KS of x has landed;
+//   * TP = 8 / KS and the batch counters are compile-time / incremental: no integer division on
+//     the way to the first weight request;
+//   * sums of squares of the norm prologues are per-wave partials that meet behind the reduction
+//     barrier, where the epilogue (which applies 1 / rms) runs anyway.
+// Same image layout, same K-slices, same MFMA order as gemv_kernel: bit-identical products.
+constexpr int kPrivJ = 4;       // 16-byte chunks per lane per activation row (slice <= 2048 elements)
+constexpr int kPrivJNorm = 2;   // norm prologues hold fp32 rows: slice <= 1024 elements
+
+template <int WD, int PRO, int EPI, int KS>
+__global__ __launch_bounds__(kGemvWaves * 64) void gemv_priv_kernel(const uint4* __restrict__ W, int NT, int KT,
+                                                                    int M, int K, int G, ProArgs p, EpiArgs e) {
+  // G = the grid size as an argument: the builtin reads the dispatch packet (two more dependent scalar loads)
+  static_assert(KS == 2 || KS == 4 || KS == 8, "wave-private staging needs a K split");
+  pin_gemv_args<PRO, EPI>(W, NT, KT, M, K, p, e);
+  pin_sgpr(G);
+  constexpr int TP = kGemvWaves / KS;
+  constexpr int TK8 = (WD == MI_W_BF16 ? 32 : 64) / 8;   // 16-byte activation chunks per k-tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* xf = reinterpret_cast<uint4*>(smem);
+  const int zero_slot = (M * K) >> 3;
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + (size_t)M * K * 2 + 16);
+  float* sc_lds = reinterpret_cast<float*>(smem + (size_t)M * K * 2 + 16 + 2 * kGemvWaves * 64 * 16);
+  float* bi_lds = sc_lds + kGemvMaxTilesPerWg * 16;
+  float* ssq_lds = bi_lds + kGemvMaxTilesPerWg * 16;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int tsub = wave / KS, kslice = wave % KS;
+  const int ktw = ceil_div(KT, KS);
+  const int kbeg = min(kslice * ktw, KT), kend = min(kbeg + ktw, KT);
+  const int klast = max(kend - 1, 0);
+  const int nb = ceil_div(ktw, kGemvU);
+  const int units = ceil_div(NT, TP);
+  const int my_units = (int)blockIdx.x < units ? ceil_div(units - (int)blockIdx.x, G) : 0;
+  const bool col_ok = c < M;
+  MI_TRACE_BEGIN();
+  MI_STAMP(0);
+
+  u32x4_t bufA[kGemvU], bufB[kGemvU];
+  int is_pass = 0, is_b = 0;     // the next batch to request
+  auto issue = [&](u32x4_t (&buf)[kGemvU]) {
+    const bool live = is_pass < my_units;
+    const int tile = min((int)(blockIdx.x + is_pass * G) * TP + tsub, NT - 1);
+    const int kt0 = kbeg + is_b * kGemvU;
+    const uint4* base = live ? W + (size_t)tile * KT * 64 + lane : W;
+    const size_t kstep = live ? 64 : 0;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) stream_load16(buf[u], base + (size_t)min(kt0 + u, klast) * kstep);
+    if (++is_b == nb) { is_b = 0; ++is_pass; }
+  };
+
+  // ---- 1. this wave's slice of the activations (requested first: vector loads retire in order) ----
+  const int c0 = kbeg * TK8, nch = (kend - kbeg) * TK8;     // 16-byte chunks [c0, c0 + nch) of every row
+  u32x4_t xv[PRO == PRO_BF16 ? 4 : 1][PRO == PRO_BF16 ? kPrivJ : 1];
+  float hv[PRO == PRO_BF16 ? 1 : kPrivJNorm][PRO == PRO_BF16 ? 1 : 4][8];
+  float pvv[PRO == PRO_NORM_PARTIAL ? kPrivJNorm : 1][PRO == PRO_NORM_PARTIAL ? 4 : 1][8];
+  float gv[PRO == PRO_BF16 ? 1 : kPrivJNorm][8];
+  if constexpr (PRO == PRO_BF16) {
+#pragma unroll
+    for (int j = 0; j < kPrivJ; ++j) {
+      if (j * 64 < nch) {                                   // wave-uniform
+        const int cc = c0 + min(lane + 64 * j, nch - 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < M) xv[m][j] = *reinterpret_cast<const u32x4_t*>(p.x + (size_t)m * p.ldx + (size_t)cc * 8);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPrivJNorm; ++j) {
+      if (j * 64 < nch) {
+        const int cc = c0 + min(lane + 64 * j, nch - 1);
+        load8(p.gain + (size_t)cc * 8, gv[j]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load8(p.resid_in + (size_t)min(m, M - 1) * K + (size_t)cc * 8, hv[j][m]);
+        if constexpr (PRO == PRO_NORM_PARTIAL) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) load8(p.partial + (size_t)min(m, M - 1) * K + (size_t)cc * 8, pvv[j][m]);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 2. scales / biases of this work-group's row-tiles, epilogue operands of its first one ----
+  const int nsc = my_units * TP * 16;
+  float scv[2] = {0.f, 0.f}, biv[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = tid + q * kGemvWaves * 64;
+    if (j < nsc) {
+      const int slot = j >> 4, r = j & 15;
+      const int tile = min((int)(blockIdx.x + (slot / TP) * G) * TP + (slot % TP), NT - 1);
+      scv[q] = e.scale[tile * 16 + r];
+      biv[q] = e.bias ? e.bias[tile * 16 + r] : 0.f;
+    }
+  }
+  const int tile0 = min((int)blockIdx.x * TP + tsub, NT - 1);
+  EpiPre<EPI> epre{};
+  // unconditional (every wave asks, the finishers use it): under a branch hipcc waits for the load
+  // at the merge point -- vmcnt(0) in front of the first weight request
+  epi_prefetch<EPI>(e, min(c, M - 1), tile0 * 16 + g * 4, epre);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 3. first weight batch, then consume the activations under its flight ----
+  issue(bufA);
+  __builtin_amdgcn_sched_barrier(0);
+  MI_STAMP(1);
+  if (lane == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);   // every wave writes the same zeros: no barrier needed
+  if constexpr (PRO == PRO_BF16) {
+#pragma unroll
+    for (int j = 0; j < kPrivJ; ++j) {
+      const int cl = lane + 64 * j;
+      if (cl < nch) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (m < M) reinterpret_cast<u32x4_t*>(xf)[xfrag_slot<WD>(c0 + cl, m, M)] = xv[m][j];
+      }
+    }
+  } else {
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < kPrivJNorm; ++j) {
+      const int cl = lane + 64 * j;
+      if (j * 64 < nch) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if constexpr (PRO == PRO_NORM_PARTIAL) hv[j][m][q] += pvv[j][m][q];
+            if (cl < nch) ss[m] = __builtin_fmaf(hv[j][m][q], hv[j][m][q], ss[m]);
+          }
+          if (cl < nch && m < M) {
+            if (p.resid_out && blockIdx.x == 0 && tsub == 0) {
+              float* o = p.resid_out + (size_t)m * K + (size_t)(c0 + cl) * 8;
+              *reinterpret_cast<float4*>(o) = make_float4(hv[j][m][0], hv[j][m][1], hv[j][m][2], hv[j][m][3]);
+              *reinterpret_cast<float4*>(o + 4) = make_float4(hv[j][m][4], hv[j][m][5], hv[j][m][6], hv[j][m][7]);
+            }
+            uint4 o4;
+            o4.x = pack_bf16x2(hv[j][m][0] * gv[j][0], hv[j][m][1] * gv[j][1]);
+            o4.y = pack_bf16x2(hv[j][m][2] * gv[j][2], hv[j][m][3] * gv[j][3]);
+            o4.z = pack_bf16x2(hv[j][m][4] * gv[j][4], hv[j][m][5] * gv[j][5]);
+            o4.w = pack_bf16x2(hv[j][m][6] * gv[j][6], hv[j][m][7] * gv[j][7]);
+            xf[xfrag_slot<WD>(c0 + cl, m, M)] = o4;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float t = wave_sum(ss[m]);
+      if (lane == 0) ssq_lds[m * 16 + wave] = t;     // read behind the K-slice reduction barrier
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = tid + q * kGemvWaves * 64;
+    if (j < nsc) {
+      sc_lds[j] = scv[q];
+      bi_lds[j] = biv[q];
+    }
+  }
+  MI_STAMP(2);
+  epi_prefetch_dependent<EPI>(e, tile0 * 16 + g * 4, epre);
+  issue(bufB);
+  MI_STAMP(3);
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int parity = 0;
+  int pr_pass = 0, pr_b = 0;     // the batch being multiplied
+  auto process = [&](u32x4_t (&buf)[kGemvU]) {
+    const int kt0 = kbeg + pr_b * kGemvU;
+#pragma unroll
+    for (int u = 0; u < kGemvU; ++u) {
+      const int kt = kt0 + u;
+      const bool ok = col_ok && kt < kend;
+      const u32x4_t w = buf[u];
+      if constexpr (WD == MI_W_BF16) {
+        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xf[ok ? (kt * 4 + g) * M + c : zero_slot]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), b, acc, 0, 0, 0);
+      } else {
+        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 0) * 4 + g) * M + c : zero_slot]);
+        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 1) * 4 + g) * M + c : zero_slot]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
+      }
+    }
+    if (++pr_b == nb) {          // row-tile done: combine the K-slices in wave order (deterministic)
+      pr_b = 0;
+      const int pass = pr_pass++;
+      const int tile = (int)(blockIdx.x + pass * G) * TP + tsub;
+      red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
+      __syncthreads();
+      if (kslice == 0 && col_ok && tile < NT) {
+        f32x4_t sum = red[(parity * kGemvWaves + wave) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < KS; ++w) {
+          const f32x4_t t = red[(parity * kGemvWaves + wave + w) * 64 + lane];
+          sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+        }
+        float rmul = 1.f;
+        if constexpr (PRO != PRO_BF16) {   // the KS waves of row-tile 0 hold one partial per K-slice
+          float tot = 0.f;
+#pragma unroll
+          for (int w = 0; w < KS; ++w) tot += ssq_lds[c * 16 + w];
+          rmul = rsqrtf(tot / (float)K + p.eps);
+        }
+        const int lslot = (pass * TP + tsub) * 16 + g * 4;
+        const float* sc4 = sc_lds + lslot;
+        const float* b4 = e.bias ? bi_lds + lslot : nullptr;
+        if (pass == 0) epilogue_pre<EPI>(e, c, tile * 16 + g * 4, sc4, b4, sum, epre, rmul);
+        else epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc4, b4, sum, rmul);
+      }
+      parity ^= 1;
+      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  const int total = my_units * nb;
+  for (int i = 0; i < total; i += 2) {
+    process(bufA);
+    if (i == 0) MI_STAMP(4);
+    issue(bufA);
+    if (i + 1 < total) process(bufB);
+    issue(bufB);
+  }
+  MI_STAMP(5);
+  MI_TRACE_END();
+}
+
+static bool gemv_priv_enabled() {
+  static const bool on = [] { const char* v = getenv("MI355X_GEMV_PRIV"); return !(v && v[0] == '0'); }();
+  return on;
+}
+// wave-private staging applies when all 8 waves stream (TP = 8 / KS), at most 4 rows, and a wave's
+// K-slice fits the per-lane register budget of the prologue
+template <int WD, int PRO>
+static bool gemv_priv_ok(int M, int KT, int ks, int tp) {
+  if (!gemv_priv_enabled() || ks < 2 || ks * tp != kGemvWaves || M > 4) return false;
+  const int nch = ceil_div(KT, ks) * (tile_k(WD) / 8);
+  return nch <= 64 * (PRO == PRO_BF16 ? kPrivJ : kPrivJNorm);
+}
+
+template <int WD, int PRO, int EPI, int KS>
+static int launch_gemv_priv(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s, int num_cu) {
+  constexpr int TP = kGemvWaves / KS;
+  const int NT = w.N / 16, KT = w.K / tile_k(WD);
+  const size_t lds = gemv_lds_bytes(M, w.K);
+  auto kern = gemv_priv_kernel<WD, PRO, EPI, KS>;
+  MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
+  const int units = ceil_div(NT, TP);
+  int grid = min(units, num_cu);
+  grid = max(grid, ceil_div(units * TP, kGemvMaxTilesPerWg));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s, reinterpret_cast<const uint4*>(w.w), NT, KT, M,
+                     w.K, grid, p, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 // (KS, TP) for NT row-tiles of KT k-tiles on `slots` resident work-groups: fewest k-tiles on the
 // busiest CU (passes x TP x KT/KS x KS), then the fewest passes, then the most streaming waves,
 // then the smallest K split.
@@ -626,6 +917,13 @@ static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArg
   int num_cu = 0;
   MI_TRY_(device_num_cu(&num_cu));
   const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
+  if (gemv_priv_ok<WD, PRO>(M, w.K / tile_k(WD), sh.ks, sh.tp)) {
+    switch (sh.ks) {
+      case 2: return launch_gemv_priv<WD, PRO, EPI, 2>(w, M, p, e, s, num_cu);
+      case 4: return launch_gemv_priv<WD, PRO, EPI, 4>(w, M, p, e, s, num_cu);
+      default: return launch_gemv_priv<WD, PRO, EPI, 8>(w, M, p, e, s, num_cu);
+    }
+  }
   switch (sh.ks) {
     case 1: return launch_gemv_ks<WD, PRO, EPI, 1>(w, M, sh.tp, p, e, s, num_cu);
     case 2: return launch_gemv_ks<WD, PRO, EPI, 2>(w, M, sh.tp, p, e, s, num_cu);

@@ -296,7 +296,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     if (decode) {
       Scope sc(c, MI_K_ATTN_DECODE);
       MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
-                                c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s));
+                                c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true));
     } else {
       Scope sc(c, MI_K_ATTN_PREFILL);
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
@@ -781,6 +781,7 @@ int mi_finalize(mi_ctx* c) {
   MI_TRY(dmalloc(&c->logits, (size_t)k.max_num_seqs * c->V_l, ws));
   if (c->collective()) MI_TRY(dmalloc(&c->logits_all, (size_t)k.tp_degree * k.max_num_seqs * c->V_l, ws));
   MI_HIP(hipMalloc(&c->attn_scratch, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd)));
+  MI_HIP(hipMemsetAsync(c->attn_scratch, 0, attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd), s));   // incl. the merge tickets
   *ws += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
   c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
   const size_t nbt = (size_t)k.max_num_seqs * c->MB_cap;
