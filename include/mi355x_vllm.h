@@ -81,10 +81,20 @@ typedef struct mi_model_config {
    * activations and run on the MX-scaled MFMA at twice the bf16 rate; token generation (HBM-bound)
    * keeps bf16 activations.  0 = weight-only everywhere. */
   int32_t prefill_fp8_activations;
+  /* Tensor parallelism inside ONE process, the reference's process model (a single worker drives
+   * every core: platform.py:166-167, neuron_worker.py:106-121): tp_rank = MI_TP_ALL_RANKS makes the
+   * context a group of tp_degree rank shards, rank r on GPU tp_device_ids[r] with a host thread of
+   * its own; every entry point below fans out and rank 0's result is returned.  All ids equal =
+   * every shard on one GPU (the single-GPU tests).  tp_transport picks the exchange between the
+   * shards: the library's own all-reduce over peer-mapped memory (xGMI), or RCCL. */
+  int32_t tp_device_ids[16];
+  int32_t tp_transport; /* MI_TP_TRANSPORT_* */
 } mi_model_config;
+#define MI_TP_ALL_RANKS (-1)
+enum { MI_TP_TRANSPORT_P2P = 0, MI_TP_TRANSPORT_RCCL = 1 };
 
 const char* mi_last_error(void);
-int mi_version(void);   /* 2 = this header; 1 lacked mi_forward_tokens, mi_op_sample, mi_tp_init_transport */
+int mi_version(void);   /* 3 = this header; 2 lacked tp_device_ids / tp_transport / MI_TP_ALL_RANKS; 1 lacked mi_forward_tokens, mi_op_sample, mi_tp_init_transport */
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out);
 int mi_ctx_destroy(mi_ctx* ctx);
@@ -170,6 +180,14 @@ typedef int (*mi_allgather_fn)(void* user, const void* send, void* recv, size_t 
 int mi_tp_init_transport(mi_ctx* ctx, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user);
 
 /* ---- per-kernel entry points (device pointers; stream may be NULL) -------------------- */
+
+/* The exchange step of an in-process tensor-parallel context (tp_rank = MI_TP_ALL_RANKS, finalized) on
+ * caller-supplied data: bufs[r] = rank r's fp32 [count] on rank r's GPU, count % 8 == 0 and at most
+ * max rows x hidden_size.  In place: every rank ends with the fp32 sum over ranks, taken in rank
+ * order (bit-identical on every rank); messages of 512 KiB (as bf16) and more -- context encoding --
+ * travel as bf16, go reduce-scatter + all-gather and round the sum to bf16 once more.  Returns
+ * after the exchange has completed on every rank. */
+int mi_op_tp_all_reduce(mi_ctx* ctx, float* const* bufs, size_t count);
 
 /* The sampler of mi_forward_tokens on caller-supplied logits: logits [B, V] fp32, sampling_params
  * [B, 3] fp32 (top_k, top_p, temperature) or NULL = greedy, tokens_out [B] int32 -- all device. */

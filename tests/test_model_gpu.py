@@ -221,3 +221,17 @@ def test_collective_path_single_rank_equals_fused_path():
         m.close()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_in_launch_attention_merge_matches_oracle():
+    """MI355X_ATTN_MERGE=1: the context splits of decode attention are merged by the last
+    work-group to finish instead of a combine launch (off by default: measured slower).  The
+    switch is read once per process, so the oracle comparisons above are re-run in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MI355X_ATTN_MERGE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                        "quantized_matches_oracle or bf16_matches_hf_golden"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

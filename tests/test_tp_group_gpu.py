@@ -1,0 +1,194 @@
+"""Tensor parallelism inside ONE process (include/mi355x_vllm.h: tp_rank = MI_TP_ALL_RANKS), the
+reference's process model (a single worker drives every core: /root/reference/vllm_neuron/
+platform.py:166-167, worker/neuron_worker.py:106-121).  A gpurun box has one GPU, so every rank
+shard is placed on device 0 (tp_device_ids all equal): the shards run on their own host threads,
+enqueue into one stream, and exchange through the same all-reduce kernels that run over xGMI when
+the shards sit on different GPUs (peer-mapped buffers, per-work-group flags, device-resident
+epochs) -- only the waiting differs: with one stream the flags are already set when a reducer
+looks at them.  What a single GPU cannot show is the flag protocol under real concurrency and the
+visibility of peer memory; DESIGN.md says so.
+
+  * exchange kernels: bit-exact against the stated rule (fp32 sum in rank order; messages of 512 KiB
+    and more travel as bf16, go reduce-scatter + all-gather and round the sum to bf16 once more);
+  * sharded models (TP 2 / 4, incl. a replicated kv head, bf16 / fp8 / int8) against the CPU oracle
+    on the reference call sequence;
+  * BASELINE config 5: Llama-3.3-70B FP8 at TP 8 with the real per-rank shapes (80 layers, H 8192,
+    8 q heads + 1 kv head, I 3584, V 16032 per rank): size-independent properties, and TP 8 against
+    TP 1 (whose down_proj, K = 28672, runs the K-chunked GEMV).
+"""
+
+import pytest
+import torch
+
+from oracle import PagedDecoderOracle
+from oracle.synth import make_prompts, make_weights, zoo_config
+from tests.helpers import decode_inputs, prefill_inputs
+from tests.test_model_gpu import BS, MAXLEN, NB, NSEQ, load_golden, scenario
+
+pytestmark = pytest.mark.gpu
+
+
+def _group_model(cfg, tp, weight_dtype, quant_type, weights=None, **over):
+    from vllm_neuron_amd._native import MI_Q, MI_TP_ALL_RANKS, MI_W, NativeModel
+    rs = cfg.rope_scaling or {}
+    kw = dict(
+        num_layers=cfg.num_layers, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads,
+        num_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+        vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+        rope_type=1 if rs else 0, rope_factor=rs.get("factor", 1.0),
+        rope_low_freq_factor=rs.get("low_freq_factor", 1.0), rope_high_freq_factor=rs.get("high_freq_factor", 4.0),
+        rope_original_max_position=rs.get("original_max_position_embeddings", 0),
+        qkv_bias=int(cfg.qkv_bias), tie_word_embeddings=int(cfg.tie_word_embeddings),
+        num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
+        weight_dtype=MI_W[weight_dtype], quant_type=MI_Q[quant_type], quantize_lm_head=1,
+        tp_degree=tp, tp_rank=MI_TP_ALL_RANKS if tp > 1 else 0, tp_device_ids=[0] * tp, device_id=0, use_graphs=1)
+    kw.update(over)
+    m = NativeModel(**kw)
+    if weights is not None:
+        m.load_state_dict(weights)                    # FULL tensors: every shard takes its slice
+    else:
+        m.init_synthetic_weights(1, 0.02)
+    m.finalize()
+    return m
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_exchange_kernels_follow_the_stated_rule(tp):
+    from oracle.paged_decoder import DecoderConfig
+    cfg = DecoderConfig(num_layers=1, hidden_size=256, num_heads=8, num_kv_heads=8, head_dim=64,
+                        intermediate_size=512, vocab_size=512, rms_norm_eps=1e-5, rope_theta=10000.0)
+    m = _group_model(cfg, tp, "bf16", "per_tensor_symmetric", max_model_len=2048, ctx_buckets=[2048],
+                     num_blocks=2 * (2048 // BS) + 1, max_num_seqs=2)
+    H = cfg.hidden_size
+    g = torch.Generator().manual_seed(tp)
+    for rows in (1, 4, 7, 300, 2048):                 # 2048 x 256 x 2 B = 1 MiB: reduce-scatter + all-gather
+        n = rows * H
+        src = [(torch.randn(n, generator=g) * (1 + r)).float() for r in range(tp)]
+        two_shot = n * 2 >= 512 * 1024 and tp > 2     # context-encoding sized: bf16 on the wire, reduce-scatter + all-gather
+        want = torch.zeros(n)
+        for t in src:                                 # rank order, fp32 accumulation
+            want += t.to(torch.bfloat16).float() if two_shot else t
+        if two_shot:
+            want = want.to(torch.bfloat16).float()
+        for rep in range(3):                          # both exchange slots, then the first again
+            bufs = [t.clone().cuda() for t in src]
+            m.tp_all_reduce(bufs)
+            for r in range(tp):
+                assert torch.equal(bufs[r].cpu(), want), (rows, rep, r)
+    m.close()
+
+
+# llama31_like: 8 q / 2 kv heads -> 4 + 1 per rank at TP 2.  tinyllama_like: 8 q heads on ONE kv
+# head -> at TP 4 every rank holds 2 q heads and a replica of the kv head (the reference skips
+# vLLM's divisibility check for exactly this case, platform.py:58-64).
+@pytest.mark.parametrize("name,tp,weight_dtype,quant_type", [
+    ("llama31_like", 2, "bf16", "per_tensor_symmetric"),
+    ("llama31_like", 2, "f8e4m3", "per_channel_symmetric"),
+    ("tinyllama_like", 4, "f8e4m3", "per_channel_symmetric"),
+    ("tinyllama_like", 2, "int8", "per_tensor_symmetric"),
+])
+def test_in_process_group_matches_oracle(name, tp, weight_dtype, quant_type):
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=1)
+    gen, _, _ = load_golden(name)
+    prompts = make_prompts(cfg.vocab_size, 0)
+    quant = None if weight_dtype == "bf16" else dict(quantized=True, quantization_dtype=weight_dtype,
+                                                     quantization_type=quant_type)
+    oracle = PagedDecoderOracle(cfg, w, NB, BS, compute="bf16", quant=quant)
+    model = _group_model(cfg, tp, weight_dtype, quant_type, weights=w)
+    worst = 0.0
+    last = None
+    for _, inp, _ in scenario(prompts, gen):
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got[:ref.shape[0]] - ref).abs().max().item())
+        last = (inp, got)
+    assert worst <= 0.06, worst                       # the bound of the single-GPU parity tests
+    assert model.forward_tokens(**last[0]).tolist() == last[1].argmax(dim=1).tolist()
+    model.close()
+
+
+# ---- BASELINE config 5: Llama-3.3-70B FP8, TP 8, max_model_len 2048, max_num_seqs 4 -----------------
+LLAMA33_70B = dict(num_layers=80, hidden_size=8192, num_heads=64, num_kv_heads=8, head_dim=128,
+                   intermediate_size=28672, vocab_size=128256, rms_norm_eps=1e-5, rope_theta=500000.0,
+                   rope_type=1, rope_factor=8.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0,
+                   rope_original_max_position=8192, qkv_bias=0, tie_word_embeddings=0)
+F_BS, F_MAXLEN, F_NSEQ = 32, 2048, 4
+F_MB = F_MAXLEN // F_BS
+F_NB = F_NSEQ * F_MB + 1
+
+
+def _llama70b(tp, layers=80):
+    from vllm_neuron_amd._native import MI_Q, MI_TP_ALL_RANKS, MI_W, NativeModel
+    geo = dict(LLAMA33_70B, num_layers=layers)
+    m = NativeModel(**geo, num_blocks=F_NB, block_size=F_BS, max_num_seqs=F_NSEQ, max_model_len=F_MAXLEN,
+                    weight_dtype=MI_W["f8e4m3"], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
+                    tp_degree=tp, tp_rank=MI_TP_ALL_RANKS if tp > 1 else 0, tp_device_ids=[0] * tp, device_id=0,
+                    use_graphs=1, ctx_buckets=[256, 512, 1024, 2048], prefill_fp8_activations=0)
+    m.init_synthetic_weights(1, 0.02)
+    m.finalize()
+    return m
+
+
+def _close(a, b, tol_max, tol_rms):
+    d = (a - b).float()
+    return d.abs().max().item() <= tol_max and d.pow(2).mean().sqrt().item() <= tol_rms
+
+
+def test_llama33_70b_tp8_properties_and_tp1_agreement():
+    """Eight rank shards with the real per-rank shapes of Llama-3.3-70B on one GPU (8.7 GB of FP8
+    weights each).  Synthetic weights are generated in logical coordinates, so the TP 8 group and
+    the TP 1 model hold the same matrices."""
+    g = torch.Generator().manual_seed(5)
+    p = torch.randint(0, 128256, (300,), generator=g).tolist()
+    blocks = (torch.randperm(F_NB - 1, generator=g) + 1).tolist()
+    rows = [blocks[i * F_MB:(i + 1) * F_MB] for i in range(F_NSEQ)]
+
+    def run(m):
+        out = {}
+        out["full"] = m.forward(**prefill_inputs(p, rows[0], F_BS, F_MAXLEN, 0))
+        out["again"] = m.forward(**prefill_inputs(p, rows[1], F_BS, F_MAXLEN, 0))       # other blocks, same prompt
+        m.forward(**prefill_inputs(p[:-1], rows[2], F_BS, F_MAXLEN, 0))
+        out["step"] = m.forward(**decode_inputs([p[-1]], [len(p) - 1], [rows[2]], F_BS, F_MAXLEN))
+        m.forward(**prefill_inputs(p[:-1], rows[3], F_BS, F_MAXLEN, 0))
+        inp2 = decode_inputs([p[-1]] * 2, [len(p) - 1] * 2, [rows[2], rows[3]], F_BS, F_MAXLEN)
+        out["step2"] = m.forward(**inp2)
+        out["ids"] = m.forward_tokens(**inp2).tolist()
+        return out
+
+    m8 = _llama70b(8)
+    a = run(m8)
+    stats8 = m8.kv_stats()
+    m8.close()
+    assert stats8["num_kv_heads_local"] == 1 and 8.0e9 < stats8["weight_bytes"] < 11.5e9, stats8
+    assert torch.isfinite(a["full"]).all() and a["full"].std() > 0.1
+    assert torch.equal(a["full"], a["again"])                          # block permutation invariance
+    assert torch.equal(a["step2"][0], a["step2"][1])                   # batch rows independent
+    assert a["ids"] == a["step2"].argmax(dim=1).tolist()               # vocabulary-parallel sampling
+    # Tolerances at this depth.  80 layers of UNSTRUCTURED random matrices at H = 8192 amplify rounding
+    # differences far more than the 32-layer 8B stack (0.019 of the logit std there): the one-GPU
+    # model's own teacher-forcing drift (context-encoding GEMMs vs token-generation GEMVs, same
+    # weights, same inputs) measures 0.068 of the logit std rms / 0.32 max here.  That is the noise
+    # floor of "the same function in another summation order"; the sharded model is held to 1.5 x
+    # that against itself and to 2 x against TP 1 (two independent orders + bf16 context-encoding
+    # exchange), and to a cosine similarity of the logit vectors above 0.98.
+    std = a["full"].std().item()
+
+    def drift(x, y):
+        d = (x - y).float()
+        return d.pow(2).mean().sqrt().item() / std, d.abs().max().item() / std, \
+            torch.nn.functional.cosine_similarity(x.float(), y.float()).min().item()
+    tf8 = drift(a["full"], a["step"])
+    print(f"70B TP8 teacher forcing (rms/std, max/std, cos): {tf8}")
+    assert tf8[0] <= 0.105 and tf8[1] <= 0.5 and tf8[2] > 0.98, tf8
+
+    m1 = _llama70b(1)
+    b = run(m1)
+    m1.close()
+    tf1 = drift(b["full"], b["step"])
+    print(f"70B TP1 teacher forcing: {tf1}")
+    assert tf1[0] <= 0.105 and tf1[1] <= 0.5 and tf1[2] > 0.98, tf1
+    assert torch.equal(b["full"], b["again"]) and torch.equal(b["step2"][0], b["step2"][1])
+    for key in ("full", "step", "step2"):
+        x = drift(a[key], b[key])
+        print(f"70B TP8 vs TP1 [{key}]: {x}")
+        assert x[0] <= 0.14 and x[1] <= 0.7 and x[2] > 0.98, (key, x)

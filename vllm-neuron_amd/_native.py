@@ -37,7 +37,12 @@ class MiModelConfig(C.Structure):
         ("weight_dtype", C.c_int32), ("quant_type", C.c_int32), ("quantize_lm_head", C.c_int32),
         ("tp_degree", C.c_int32), ("tp_rank", C.c_int32), ("device_id", C.c_int32),
         ("use_graphs", C.c_int32), ("prefill_fp8_activations", C.c_int32),
+        ("tp_device_ids", C.c_int32 * 16), ("tp_transport", C.c_int32),
     ]
+
+
+MI_TP_ALL_RANKS = -1          # tp_rank: every rank shard inside this process (include/mi355x_vllm.h)
+MI_TP_TRANSPORT = {"p2p": 0, "rccl": 1}
 
 
 class MiKvStats(C.Structure):
@@ -76,6 +81,7 @@ _SIGS = {
     "mi_tp_unique_id": (C.c_int, [C.c_void_p]),
     "mi_tp_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_tp_init_transport": (C.c_int, [C.c_void_p, MI_ALLREDUCE_FN, MI_ALLGATHER_FN, C.c_void_p]),
+    "mi_op_tp_all_reduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "mi_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -142,6 +148,11 @@ class NativeModel:
         self.lib = load_library()
         c = MiModelConfig()
         buckets = list(cfg.pop("ctx_buckets", None) or [])
+        tp_devices = list(cfg.pop("tp_device_ids", None) or [])
+        if len(tp_devices) > 16:
+            raise ValueError("tp_device_ids: at most 16 ranks")
+        for i, d in enumerate(tp_devices):
+            c.tp_device_ids[i] = int(d)
         for k, v in cfg.items():
             if not hasattr(c, k):
                 raise ValueError(f"unknown native config field {k!r}")
@@ -198,6 +209,13 @@ class NativeModel:
         self._xport = (MI_ALLREDUCE_FN(lambda user, buf, n, st: int(all_reduce(buf, n, st))),
                        MI_ALLGATHER_FN(lambda user, snd, rcv, n, st: int(all_gather(snd, rcv, n, st))))  # keep alive
         check(self.lib.mi_tp_init_transport(self._ctx, self._xport[0], self._xport[1], None))
+
+    def tp_all_reduce(self, tensors) -> None:
+        """In-process tensor-parallel context only: all-reduce the fp32 device tensors (one per
+        rank, on that rank's GPU) in place through the library's exchange kernels."""
+        n = tensors[0].numel()
+        ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        check(self.lib.mi_op_tp_all_reduce(self._ctx, ptrs, n))
 
     def set_num_blocks(self, num_blocks: int) -> None:
         check(self.lib.mi_set_num_blocks(self._ctx, num_blocks))

@@ -12,8 +12,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["linear_kernels.hip", "attn_kernels.hip", "misc_kernels.hip", "model.hip"]
-HEADERS = ["mi_common.h", "linear_kernels.h", "attn_kernels.h", "misc_kernels.h",
+SOURCES = ["linear_kernels.hip", "attn_kernels.hip", "misc_kernels.hip", "model.hip", "tp_group.hip"]
+HEADERS = ["mi_common.h", "linear_kernels.h", "attn_kernels.h", "misc_kernels.h", "model_internal.h", "tp_group.h",
            os.path.join("..", "..", "include", "mi355x_vllm.h")]
 LIB = os.path.join(HERE, "libmi355x_vllm.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value",

@@ -14,8 +14,6 @@
 // The residual stream is fp32 and ping-pongs between two buffers: the norm prologue of the
 // NEXT kernel folds in the previous partial, so a row-parallel output needs no extra pass.
 
-#include <rccl/rccl.h>
-
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -42,87 +40,8 @@ using namespace mi;
     if (_rc != MI_OK) return _rc; \
   } while (0)
 
-namespace {
-
-struct Linear {
-  void* w = nullptr;
-  float* scale = nullptr;
-  float* bias = nullptr;
-  int N = 0, K = 0, wd = MI_W_BF16;
-  LinearW view() const { return LinearW{w, N, K, wd}; }
-  size_t bytes() const { return (size_t)N * K * elem_bytes(wd); }
-};
-
-struct LayerW {
-  Linear qkv, o, gu, down;
-  float* g_in = nullptr;
-  float* g_post = nullptr;
-};
-
-struct Prof {
-  bool on = false;
-  std::vector<hipEvent_t> ev;  // pairs
-  std::vector<int> cls;
-  int launches[MI_K_NUM] = {0};
-  float ms[MI_K_NUM] = {0};
-  double gemv_bytes = 0;
-};
-
-}  // namespace
-
-struct mi_ctx {
-  mi_model_config cfg;
-  hipStream_t stream = nullptr;
-  bool finalized = false;
-  // per-rank geometry
-  int H = 0, hd = 0, nh_l = 0, nkv_l = 0, kvh0 = 0, q_dim = 0, kv_dim = 0, I_l = 0, V_l = 0, max_rows = 0;
-  std::vector<LayerW> layers;
-  uint16_t* embed = nullptr;
-  Linear lm_head;
-  float* g_final = nullptr;
-  bool have_lm_head = false;
-  // KV pool: [L][2][NB][nkv_l][bs][hd] bf16
-  uint16_t* kv_pool = nullptr;
-  size_t kv_half = 0;  // elements of one K (or V) pool of one layer
-  float *rope_cos = nullptr, *rope_sin = nullptr;
-  // weight-load staging
-  void* stage_raw = nullptr;
-  float* stage_f32 = nullptr;
-  float* rowmax = nullptr;
-  size_t stage_elems = 0;
-  // activations
-  float* resid[2] = {nullptr, nullptr};
-  float* partial = nullptr;
-  uint16_t *xn = nullptr, *qbuf = nullptr, *attn_out = nullptr, *act = nullptr;
-  uint8_t* x8 = nullptr;        // FP8-activation GEMM input [rows, K]
-  float* x8_scale = nullptr;    // its per-token scales [rows]
-  float* splitk_ws = nullptr;   // fp32 K-split slabs of short-prompt GEMMs
-  size_t splitk_ws_bytes = 0;
-  float* logits = nullptr;      // [max_num_seqs, V_l]
-  float* logits_all = nullptr;  // [tp, max_num_seqs, V_l] (tp > 1)
-  void* attn_scratch = nullptr;
-  // step inputs
-  int32_t *d_ids = nullptr, *d_pos = nullptr, *d_slots = nullptr, *d_bt = nullptr, *d_ctx = nullptr;
-  int32_t *h_ids = nullptr, *h_pos = nullptr, *h_slots = nullptr, *h_bt = nullptr, *h_ctx = nullptr;
-  // the five input arrays above are slices of ONE device block / ONE pinned block: one H2D per call
-  int32_t *d_inputs = nullptr, *h_inputs = nullptr;
-  size_t inputs_elems = 0;
-  float* h_logits = nullptr;
-  // on-device sampling: (top_k, top_p, temperature) rows and the sampled ids
-  float *d_sparams = nullptr, *h_sparams = nullptr;
-  int32_t *d_tokens = nullptr, *h_tokens = nullptr;
-  int MB_cap = 0;
-  size_t weight_bytes = 0, workspace_bytes = 0, kv_bytes = 0;
-  std::map<int, hipGraphExec_t> graphs;  // token-generation graph per (B * 65536 + MB)
-  int last_B = 0, last_MB = 0;           // shape of the last token-generation call (mi_replay_decode)
-  Prof prof;
-  ncclComm_t comm = nullptr;
-  // caller-supplied collectives in place of RCCL (mi_tp_init_transport)
-  mi_allreduce_fn xport_allreduce = nullptr;
-  mi_allgather_fn xport_allgather = nullptr;
-  void* xport_user = nullptr;
-  bool collective() const { return comm != nullptr || xport_allreduce != nullptr; }
-};
+#include "model_internal.h"
+#include "tp_group.h"
 
 namespace {
 
@@ -247,6 +166,7 @@ static HostTiming g_ht;
 int all_reduce_partial(mi_ctx* c, int rows) {
   if (!c->collective()) return MI_OK;
   Scope sc(c, MI_K_COMM);
+  if (c->grp) return group_all_reduce(c, c->partial, (size_t)rows * c->H);
   if (c->xport_allreduce) {
     if (c->xport_allreduce(c->xport_user, c->partial, (size_t)rows * c->H, c->stream) != 0) {
       set_error("all-reduce transport callback failed");
@@ -357,7 +277,9 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     e.out_f32 = c->logits; e.ld_out = c->V_l;
     MI_TRY(run_linear(c, c->lm_head, logits_rows, PRO_NORM, p, EPI_F32, e));
   }
-  if (c->xport_allgather) {
+  if (c->grp) {
+    // in-process group: every shard hands its vocabulary slice to the host (or to rank 0's sampler) itself
+  } else if (c->xport_allgather) {
     Scope sc(c, MI_K_COMM);
     if (c->xport_allgather(c->xport_user, c->logits, c->logits_all, (size_t)k.max_num_seqs * c->V_l, s) != 0) {
       set_error("all-gather transport callback failed");
@@ -384,6 +306,14 @@ int fetch_logits(mi_ctx* c, int nrows, float* out) {
     g_ht.lap(4);
     memcpy(out, c->h_logits, (size_t)nrows * V * 4);
     g_ht.lap(5);
+    return MI_OK;
+  }
+  if (c->grp) {   // this shard's vocabulary slice, straight into its columns of the caller's rows
+    MI_HIP(hipMemcpyAsync(c->h_logits, c->logits, (size_t)nrows * c->V_l * 4, hipMemcpyDeviceToHost, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    MI_TRY(group_check_errors(c));
+    for (int b = 0; b < nrows; ++b)
+      memcpy(out + (size_t)b * V + (size_t)k.tp_rank * c->V_l, c->h_logits + (size_t)b * c->V_l, (size_t)c->V_l * 4);
     return MI_OK;
   }
   const size_t per_rank = (size_t)k.max_num_seqs * c->V_l;
@@ -559,14 +489,28 @@ int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
 extern "C" {
 
 const char* mi_last_error(void) { return mi::g_err.c_str(); }
-int mi_version(void) { return 2; }   // 2: + mi_forward_tokens, mi_op_sample, mi_tp_init_transport (additions only)
+int mi_version(void) { return 3; }   // 3: + in-process tensor parallelism (tp_rank = MI_TP_ALL_RANKS, tp_device_ids, tp_transport)
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   MI_CHECK(cfg && out, "null argument");
   const mi_model_config& k = *cfg;
   MI_CHECK(k.num_layers > 0 && k.hidden_size > 0 && k.num_heads > 0 && k.num_kv_heads > 0, "bad geometry");
   MI_CHECK(k.head_dim == 64 || k.head_dim == 128, "head_dim must be 64 or 128");
-  MI_CHECK(k.tp_degree >= 1 && k.tp_rank >= 0 && k.tp_rank < k.tp_degree, "bad tp_degree / tp_rank");
+  if (k.tp_rank == MI_TP_ALL_RANKS && k.tp_degree > 1) {   // every rank shard inside this process (tp_group.h)
+    mi_ctx* f = new mi_ctx();
+    f->cfg = k;
+    int rc = group_create(k, f);
+    if (rc != MI_OK) {
+      const std::string keep = mi::g_err;
+      group_destroy(f->owned_group);
+      delete f;
+      set_error(keep);
+      return rc;
+    }
+    *out = f;
+    return MI_OK;
+  }
+  MI_CHECK(k.tp_degree >= 1 && (k.tp_rank >= 0 || k.tp_degree == 1) && k.tp_rank < k.tp_degree, "bad tp_degree / tp_rank");
   MI_CHECK(k.num_heads % k.tp_degree == 0, "num_heads must divide by tp_degree");
   MI_CHECK(k.num_heads % k.num_kv_heads == 0, "num_heads must be a multiple of num_kv_heads");
   MI_CHECK(k.intermediate_size % k.tp_degree == 0 && k.vocab_size % k.tp_degree == 0, "intermediate/vocab must divide by tp_degree");
@@ -586,6 +530,7 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
 
   mi_ctx* c = new mi_ctx();
   c->cfg = k;
+  if (c->cfg.tp_rank < 0) c->cfg.tp_rank = 0;   // MI_TP_ALL_RANKS of one rank
   MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   const int T = k.tp_degree;
   c->H = k.hidden_size;
@@ -623,11 +568,17 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
 
 int mi_ctx_destroy(mi_ctx* c) {
   if (!c) return MI_OK;
+  if (c->owned_group) {
+    group_destroy(c->owned_group);
+    delete c;
+    return MI_OK;
+  }
   g_ht.report();
   hipSetDevice(c->cfg.device_id);
   hipStreamSynchronize(c->stream);
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->grp && c->grp->lockstep && c->cfg.tp_rank != 0) hipStreamSynchronize(c->stream);
   auto fl = [](Linear& L) { hipFree(L.w); hipFree(L.scale); hipFree(L.bias); };
   for (auto& W : c->layers) { fl(W.qkv); fl(W.o); fl(W.gu); fl(W.down); hipFree(W.g_in); hipFree(W.g_post); }
   fl(c->lm_head);
@@ -637,13 +588,15 @@ int mi_ctx_destroy(mi_ctx* c) {
   for (void* p : ptrs) hipFree(p);
   void* hptrs[] = {c->h_inputs, c->h_sparams, c->h_tokens, c->h_logits};
   for (void* p : hptrs) if (p) hipHostFree(p);
-  hipStreamDestroy(c->stream);
+  if (c->stream_owned) hipStreamDestroy(c->stream);
   delete c;
   return MI_OK;
 }
 
 int mi_load_weight(mi_ctx* c, const char* name_c, const void* host, int32_t dtype, const int64_t* shape, int32_t ndim) {
   MI_CHECK(c && name_c && host && shape, "null argument");
+  if (c->owned_group)
+    return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_load_weight(rc, name_c, host, dtype, shape, ndim); });
   MI_CHECK(!c->finalized, "mi_load_weight after mi_finalize");
   MI_CHECK(dtype == MI_F32 || dtype == MI_BF16, "weights must be fp32 or bf16 on the host");
   MI_CHECK(ndim == 1 || ndim == 2, "weights must be 1-D or 2-D");
@@ -669,7 +622,10 @@ int mi_load_weight(mi_ctx* c, const char* name_c, const void* host, int32_t dtyp
 }
 
 int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
-  MI_CHECK(c && !c->finalized, "bad state");
+  MI_CHECK(c, "null argument");
+  if (c->owned_group)
+    return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_init_synthetic_weights(rc, seed, std); });
+  MI_CHECK(!c->finalized, "bad state");
   MI_HIP(hipSetDevice(c->cfg.device_id));
   const mi_model_config& k = c->cfg;
   uint64_t tid = 1;
@@ -712,14 +668,26 @@ int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
 }
 
 int mi_set_num_blocks(mi_ctx* c, int32_t num_blocks) {
-  MI_CHECK(c && !c->finalized, "mi_set_num_blocks after mi_finalize");
+  MI_CHECK(c, "null argument");
+  if (c->owned_group) {
+    c->cfg.num_blocks = num_blocks;
+    return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_set_num_blocks(rc, num_blocks); });
+  }
+  MI_CHECK(!c->finalized, "mi_set_num_blocks after mi_finalize");
   MI_CHECK(num_blocks >= 2, "num_blocks must include the null block and at least one real block");
   c->cfg.num_blocks = num_blocks;
   return MI_OK;
 }
 
 int mi_finalize(mi_ctx* c) {
-  MI_CHECK(c && !c->finalized, "bad state");
+  MI_CHECK(c, "null argument");
+  if (c->owned_group) {
+    MI_CHECK(!c->finalized, "bad state");
+    MI_TRY(group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_finalize(rc); }));
+    c->finalized = true;
+    return MI_OK;
+  }
+  MI_CHECK(!c->finalized, "bad state");
   MI_CHECK(c->have_lm_head, "lm_head.weight (or tied embed_tokens) was never loaded");
   MI_CHECK(c->cfg.tp_degree == 1 || c->collective(), "tp_degree > 1: call mi_tp_init before mi_finalize");
   const mi_model_config& k = c->cfg;
@@ -810,6 +778,7 @@ int mi_finalize(mi_ctx* c) {
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tokens), (size_t)k.max_num_seqs * 4, hipHostMallocDefault));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), (size_t)k.max_num_seqs * k.vocab_size * 4, hipHostMallocDefault));
   MI_HIP(hipStreamSynchronize(s));
+  if (c->grp) MI_TRY(group_alloc_exchange(c));
   c->finalized = true;
   return MI_OK;
 }
@@ -821,6 +790,17 @@ static int sample_on_device(mi_ctx* c, int nrows, int row0, const float* samplin
                             int64_t* tokens_out) {
   const mi_model_config& k = c->cfg;
   hipStream_t s = c->stream;
+  if (c->grp) {   // vocabulary slices -> rank 0's gather buffer (peer copy), rank 0 samples
+    mi_ctx* c0 = c->grp->ranks[0];
+    const size_t per_rank = (size_t)k.max_num_seqs * c->V_l;
+    float* dst = c0->logits_all + (size_t)k.tp_rank * per_rank;
+    if (c->grp->lockstep) MI_HIP(hipMemcpyAsync(dst, c->logits, per_rank * 4, hipMemcpyDeviceToDevice, s));
+    else MI_HIP(hipMemcpyPeerAsync(dst, c0->cfg.device_id, c->logits, k.device_id, per_rank * 4, s));
+    MI_HIP(hipStreamSynchronize(s));
+    MI_TRY(group_check_errors(c));
+    MI_CHECK(c->grp->bar->wait(), "tensor-parallel group aborted");
+    if (k.tp_rank != 0) return MI_OK;
+  }
   const float* dparams = nullptr;
   if (sampling_params) {
     memcpy(c->h_sparams, sampling_params + (size_t)row0 * 3, (size_t)nrows * 3 * 4);
@@ -845,6 +825,11 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
                         const int64_t* seq_ids, const int64_t* block_table, int32_t MB, const int64_t* slot_mapping,
                         int32_t SM, const int64_t* full_context_lens, const int64_t* computed_context_lens,
                         float* logits_out, const float* sampling_params, uint64_t seed, int64_t* tokens_out) {
+  if (c && c->owned_group)   // the same call on every rank shard, each on its own thread; the shards fill disjoint columns
+    return group_run(c->owned_group, [&](mi_ctx* rc, int) {
+      return forward_impl(rc, B, S, input_ids, position_ids, seq_ids, block_table, MB, slot_mapping, SM, full_context_lens,
+                          computed_context_lens, logits_out, sampling_params, seed, tokens_out);
+    });
   MI_CHECK(c && c->finalized, "mi_forward before mi_finalize");
   MI_CHECK(input_ids && position_ids && block_table && slot_mapping && full_context_lens && computed_context_lens, "null argument");
   MI_CHECK((logits_out != nullptr) != (tokens_out != nullptr), "exactly one of logits_out / tokens_out");
@@ -954,6 +939,13 @@ int mi_forward_tokens(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids,
 
 int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
   MI_CHECK(c && c->finalized && elapsed_ms, "bad argument");
+  if (c->owned_group) {   // every shard replays its step; the slowest rank is the step
+    std::vector<float> ms(c->owned_group->T, 0.f);
+    MI_TRY(group_run(c->owned_group, [&](mi_ctx* rc, int r) { return mi_replay_decode(rc, steps, &ms[r]); }));
+    *elapsed_ms = 0.f;
+    for (float v : ms) *elapsed_ms = std::max(*elapsed_ms, v);
+    return MI_OK;
+  }
   MI_CHECK(c->last_B > 0, "mi_replay_decode needs a preceding token-generation mi_forward");
   MI_CHECK(steps >= 1, "steps must be >= 1");
   MI_HIP(hipSetDevice(c->cfg.device_id));
@@ -972,6 +964,8 @@ int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
 
 int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {
   MI_CHECK(c && o, "null argument");
+  if (c->owned_group)   // per-GPU figures of rank 0 (every shard holds the same amounts)
+    return group_run(c->owned_group, [&](mi_ctx* rc, int r) { return r == 0 ? mi_kv_stats(rc, o) : MI_OK; });
   MI_HIP(hipSetDevice(c->cfg.device_id));
   size_t fr = 0, tot = 0;
   MI_HIP(hipMemGetInfo(&fr, &tot));
@@ -983,10 +977,14 @@ int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {
   return MI_OK;
 }
 
-void* mi_stream(mi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* mi_stream(mi_ctx* c) {
+  if (c && c->owned_group) return (void*)c->owned_group->ranks[0]->stream;
+  return c ? (void*)c->stream : nullptr;
+}
 
 int mi_profile_enable(mi_ctx* c, int32_t on) {
   MI_CHECK(c, "null argument");
+  if (c->owned_group) return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_profile_enable(rc, on); });
   MI_TRY(prof_collect(c));
   c->prof.on = on != 0;
   if (on) {
@@ -998,6 +996,12 @@ int mi_profile_enable(mi_ctx* c, int32_t on) {
 }
 int mi_profile_read(mi_ctx* c, int32_t* launches, float* ms, double* gemv_weight_bytes) {
   MI_CHECK(c && launches && ms, "null argument");
+  if (c->owned_group)   // rank 0's timeline (the shards run the same launches)
+    return group_run(c->owned_group, [&](mi_ctx* rc, int r) {
+      int32_t l2[MI_K_NUM];
+      float m2[MI_K_NUM];
+      return r == 0 ? mi_profile_read(rc, launches, ms, gemv_weight_bytes) : mi_profile_read(rc, l2, m2, nullptr);
+    });
   MI_TRY(prof_collect(c));
   for (int i = 0; i < MI_K_NUM; ++i) { launches[i] = c->prof.launches[i]; ms[i] = c->prof.ms[i]; }
   if (gemv_weight_bytes) *gemv_weight_bytes = c->prof.gemv_bytes;
@@ -1015,6 +1019,7 @@ int mi_tp_unique_id(void* out128) {
 }
 int mi_tp_init(mi_ctx* c, const void* id128) {
   MI_CHECK(c && id128, "null argument");
+  MI_CHECK(!c->owned_group && !c->grp, "mi_tp_init on an in-process tensor-parallel context");
   MI_CHECK(!c->comm, "mi_tp_init called twice");
   MI_HIP(hipSetDevice(c->cfg.device_id));
   ncclUniqueId id;
@@ -1026,6 +1031,7 @@ int mi_tp_init(mi_ctx* c, const void* id128) {
 
 int mi_tp_init_transport(mi_ctx* c, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user) {
   MI_CHECK(c && all_reduce && all_gather, "null argument");
+  MI_CHECK(!c->owned_group, "mi_tp_init_transport on an in-process tensor-parallel context");
   MI_CHECK(!c->collective(), "tensor-parallel transport already set");
   MI_CHECK(!c->finalized, "mi_tp_init_transport must precede mi_finalize");
   c->xport_allreduce = all_reduce;
@@ -1046,6 +1052,15 @@ int mi_debug_copy(mi_ctx* c, int which, void* host, size_t bytes) {
 #endif
 
 // ---- per-kernel entry points ------------------------------------------------------------
+int mi_op_tp_all_reduce(mi_ctx* c, float* const* bufs, size_t count) {
+  MI_CHECK(c && c->owned_group && c->finalized && bufs, "mi_op_tp_all_reduce needs a finalized in-process tensor-parallel context");
+  return group_run(c->owned_group, [&](mi_ctx* rc, int r) -> int {
+    MI_TRY(group_all_reduce(rc, bufs[r], count));
+    MI_HIP(hipStreamSynchronize(rc->stream));
+    return group_check_errors(rc);
+  });
+}
+
 int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
                  int32_t* tokens_out, void* stream) {
   MI_CHECK(logits && tokens_out && B >= 1 && V >= 1, "bad argument");

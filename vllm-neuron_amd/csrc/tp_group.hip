@@ -1,0 +1,491 @@
+// Tensor parallelism inside one process: rank threads, the hand-written all-reduce over
+// peer-mapped memory, and the fan-out of the C ABI.  See tp_group.h.
+
+#include "tp_group.h"
+
+#include <cstdio>
+#include <cstring>
+
+#include "model_internal.h"
+
+extern "C" const char* mi_last_error(void);
+
+namespace mi {
+
+// =====================================================================================
+// host barrier
+// =====================================================================================
+bool HostBarrier::wait() {
+  std::unique_lock<std::mutex> lk(mu_);
+  if (aborted_) return false;
+  const unsigned gen = gen_;
+  if (++count_ == n_) {
+    count_ = 0;
+    ++gen_;
+    cv_.notify_all();
+    return true;
+  }
+  cv_.wait(lk, [&] { return gen_ != gen || aborted_; });
+  return !aborted_;
+}
+void HostBarrier::abort() {
+  std::lock_guard<std::mutex> lk(mu_);
+  aborted_ = true;
+  cv_.notify_all();
+}
+void HostBarrier::reset() {
+  std::lock_guard<std::mutex> lk(mu_);
+  aborted_ = false;
+  count_ = 0;
+}
+
+// =====================================================================================
+// exchange kernels
+// =====================================================================================
+constexpr int kArThreads = 256;
+constexpr unsigned kArSpinMax = 1u << 20;   // bounded wait: ~1-2 s, then the error word is set and the kernel goes on
+
+enum { AR_EPOCH_PUB = 0, AR_EPOCH_RS = 1, AR_TICKET_PUB = 4, AR_TICKET_RS = 5, AR_ERROR = 8, AR_WORDS = 16 };
+
+struct ArGeom {
+  int T, r, G;          // ranks, this rank, work-groups
+  int pubG;             // work-groups of the publish kernel of this exchange
+  unsigned chunks;      // 16-byte (8 x bf16) chunks of the message
+  unsigned cpw;         // chunks per work-group (one-shot) / per work-group inside a slice (two-shot)
+  unsigned cps;         // chunks per rank slice (two-shot)
+  size_t cap;           // elements per exchange slot
+  size_t ycap;          // elements per reduced-slice slot
+};
+
+__device__ __forceinline__ bool flag_reached(const uint32_t* p, uint32_t e) {
+  const uint32_t v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  return (int32_t)(v - e) >= 0;
+}
+// wait until work-groups 0 .. nG-1 of every peer have signalled epoch e in this rank's flag block
+__device__ __forceinline__ void wait_flags(const uint32_t* flags, int T, int self, int nG, uint32_t e, uint32_t* err) {
+  for (int i = threadIdx.x; i < T * nG; i += blockDim.x) {
+    const int p = i / nG, w = i - p * nG;
+    if (p == self) continue;   // a rank does not signal itself
+    unsigned it = 0;
+    while (!flag_reached(flags + p * kArMaxBlocks + w, e)) {
+      if (++it >= kArSpinMax) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: drop stale lines of the peers' buffers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+// the last work-group of a kernel advances its epoch counter (every work-group read it at entry)
+__device__ __forceinline__ void advance_epoch(uint32_t* ctr, int epoch_idx, int ticket_idx, uint32_t e, int G) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ctr + ticket_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (uint32_t)(G - 1)) {
+      __hip_atomic_store(ctr + ticket_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctr + epoch_idx, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+__device__ __forceinline__ uint32_t read_epoch(const uint32_t* ctr, int idx) {
+  return __hip_atomic_load(ctr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ u32x4_t pack8(const float4 a, const float4 b) {
+  return u32x4_t{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+}
+__device__ __forceinline__ void add8(float (&acc)[8], const u32x4_t v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[2 * k] += bf16lo_to_f32(v[k]);
+    acc[2 * k + 1] += bf16hi_to_f32(v[k]);
+  }
+}
+__device__ __forceinline__ void store8(float* o, const float (&a)[8]) {
+  *reinterpret_cast<float4*>(o) = make_float4(a[0], a[1], a[2], a[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(a[4], a[5], a[6], a[7]);
+}
+
+// Wire format of an exchange slot: F32 = the fp32 partial as it is (token generation: the message is
+// latency-bound, the sum equals the one-GPU sum up to its order); otherwise bf16 (context encoding:
+// 2 (T-1)/T x 32 MiB per rank and exchange at N = 2048, H = 8192 -- half the bytes on the links).
+// `base` is the slot in units of the wire element.
+template <bool F32>
+__device__ __forceinline__ void wire_store8(void* base, size_t ch, const float4 a, const float4 b) {
+  if constexpr (F32) {
+    float* p = reinterpret_cast<float*>(base) + ch * 8;
+    *reinterpret_cast<float4*>(p) = a;
+    *reinterpret_cast<float4*>(p + 4) = b;
+  } else {
+    *reinterpret_cast<u32x4_t*>(reinterpret_cast<uint16_t*>(base) + ch * 8) = pack8(a, b);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void wire_add8(float (&acc)[8], const void* base, size_t ch) {
+  if constexpr (F32) {
+    const float* p = reinterpret_cast<const float*>(base) + ch * 8;
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+  } else {
+    add8(acc, *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint16_t*>(base) + ch * 8));
+  }
+}
+template <bool F32>
+__device__ __forceinline__ const void* wire_slot(const uint16_t* buf, uint32_t e, size_t cap) {
+  return reinterpret_cast<const unsigned char*>(buf) + (size_t)(e & 1) * cap * 4;   // slots are fp32-sized whatever travels
+}
+
+// fp32 partial -> this rank's exchange slot; per work-group: release, then one flag per peer
+template <bool F32>
+__global__ __launch_bounds__(kArThreads) void ar_publish_kernel(const float* __restrict__ partial, ArPeers P, ArGeom ge,
+                                                                uint32_t* __restrict__ ctr) {
+  const int w = blockIdx.x;
+  const uint32_t e = read_epoch(ctr, AR_EPOCH_PUB) + 1;
+  void* slot = const_cast<void*>(wire_slot<F32>(P.xbuf[ge.r], e, ge.cap));
+  const unsigned c0 = (unsigned)w * ge.cpw, c1 = min(c0 + ge.cpw, ge.chunks);
+  for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+    const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)ch * 8);
+    const float4 b = *reinterpret_cast<const float4*>(partial + (size_t)ch * 8 + 4);
+    wire_store8<F32>(slot, ch, a, b);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope, every storing thread
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < ge.T && (int)threadIdx.x != ge.r)
+    __hip_atomic_store(P.flag1[threadIdx.x] + ge.r * kArMaxBlocks + w, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  advance_epoch(ctr, AR_EPOCH_PUB, AR_TICKET_PUB, e, ge.G);
+}
+
+// one-shot: sum the range of this work-group over all ranks, in rank order
+template <bool F32>
+__global__ __launch_bounds__(kArThreads) void ar_reduce_kernel(float* __restrict__ out, ArPeers P, ArGeom ge,
+                                                               uint32_t* __restrict__ ctr) {
+  const int w = blockIdx.x;
+  const uint32_t e = read_epoch(ctr, AR_EPOCH_PUB);   // the publish kernel in front of this one has advanced it
+  // the peers' flags for work-group w: word p * kArMaxBlocks + w of this rank's block
+  {
+    const int t = threadIdx.x;
+    if (t < ge.T && t != ge.r) {
+      unsigned it = 0;
+      while (!flag_reached(P.flag1[ge.r] + t * kArMaxBlocks + w, e)) {
+        if (++it >= kArSpinMax) {
+          __hip_atomic_store(ctr + AR_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const unsigned c0 = (unsigned)w * ge.cpw, c1 = min(c0 + ge.cpw, ge.chunks);
+  for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < ge.T; ++p) wire_add8<F32>(acc, wire_slot<F32>(P.xbuf[p], e, ge.cap), ch);
+    store8(out + (size_t)ch * 8, acc);
+  }
+}
+
+// two-shot, step 1: this rank reduces ITS slice [r * cps, (r + 1) * cps) and publishes the bf16 result
+__global__ __launch_bounds__(kArThreads) void ar_reduce_scatter_kernel(float* __restrict__ out, ArPeers P, ArGeom ge,
+                                                                       uint32_t* __restrict__ ctr) {
+  const int w = blockIdx.x;
+  const uint32_t e = read_epoch(ctr, AR_EPOCH_PUB);
+  const uint32_t e2 = read_epoch(ctr, AR_EPOCH_RS) + 1;
+  // any publishing work-group of a peer may have written part of this range: wait for all of them
+  wait_flags(P.flag1[ge.r], ge.T, ge.r, ge.pubG, e, ctr + AR_ERROR);
+  uint16_t* yslot = P.ybuf[ge.r] + (size_t)(e2 & 1) * ge.ycap;
+  const unsigned s0 = min((unsigned)ge.r * ge.cps, ge.chunks), s1 = min(s0 + ge.cps, ge.chunks);
+  const unsigned c0 = min(s0 + (unsigned)w * ge.cpw, s1), c1 = min(c0 + ge.cpw, s1);
+  for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < ge.T; ++p) wire_add8<false>(acc, wire_slot<false>(P.xbuf[p], e, ge.cap), ch);
+    const u32x4_t pk = pack8(make_float4(acc[0], acc[1], acc[2], acc[3]), make_float4(acc[4], acc[5], acc[6], acc[7]));
+    *reinterpret_cast<u32x4_t*>(yslot + (size_t)(ch - s0) * 8) = pk;
+    float rounded[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // the owner keeps what the others will read
+    add8(rounded, pk);
+    store8(out + (size_t)ch * 8, rounded);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if ((int)threadIdx.x < ge.T && (int)threadIdx.x != ge.r)
+    __hip_atomic_store(P.flag2[threadIdx.x] + ge.r * kArMaxBlocks + w, e2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  advance_epoch(ctr, AR_EPOCH_RS, AR_TICKET_RS, e2, ge.G);
+}
+
+// two-shot, step 2: fetch every other rank's reduced slice
+__global__ __launch_bounds__(kArThreads) void ar_gather_kernel(float* __restrict__ out, ArPeers P, ArGeom ge,
+                                                               uint32_t* __restrict__ ctr) {
+  const int w = blockIdx.x;
+  const uint32_t e2 = read_epoch(ctr, AR_EPOCH_RS);
+  wait_flags(P.flag2[ge.r], ge.T, ge.r, ge.G, e2, ctr + AR_ERROR);
+  for (int p = 0; p < ge.T; ++p) {
+    if (p == ge.r) continue;
+    const uint16_t* yslot = P.ybuf[p] + (size_t)(e2 & 1) * ge.ycap;
+    const unsigned s0 = min((unsigned)p * ge.cps, ge.chunks), s1 = min(s0 + ge.cps, ge.chunks);
+    const unsigned c0 = min(s0 + (unsigned)w * ge.cpw, s1), c1 = min(c0 + ge.cpw, s1);
+    for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      add8(v, *reinterpret_cast<const u32x4_t*>(yslot + (size_t)(ch - s0) * 8));
+      store8(out + (size_t)ch * 8, v);
+    }
+  }
+}
+
+// =====================================================================================
+// group plumbing
+// =====================================================================================
+static void rank_thread(mi_group* g, int r, int device) {
+  hipSetDevice(device);
+  unsigned seen = 0;
+  for (;;) {
+    std::function<int(mi_ctx*, int)> fn;
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv_job.wait(lk, [&] { return g->stop || g->job_gen != seen; });
+      if (g->stop) return;
+      seen = g->job_gen;
+      fn = g->job;
+    }
+    int rc = MI_EHIP;
+    std::string msg;
+    try {
+      rc = fn(g->ranks[r], r);
+      if (rc != MI_OK) msg = mi_last_error();
+    } catch (const std::exception& ex) {
+      msg = ex.what();
+    }
+    if (rc != MI_OK && g->bar) g->bar->abort();   // peers waiting at an exchange barrier must not wait for ever
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->rc[r] = rc;
+      g->err[r] = msg;
+      if (--g->pending == 0) g->cv_done.notify_all();
+    }
+  }
+}
+
+int group_run(mi_group* g, const std::function<int(mi_ctx*, int)>& fn) {
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->job = fn;
+    g->pending = g->T;
+    ++g->job_gen;
+    g->cv_job.notify_all();
+    g->cv_done.wait(lk, [&] { return g->pending == 0; });
+  }
+  int first = MI_OK;
+  std::string msg;
+  for (int r = 0; r < g->T; ++r)
+    if (g->rc[r] != MI_OK && first == MI_OK) {
+      first = g->rc[r];
+      msg = "tp rank " + std::to_string(r) + ": " + g->err[r];
+    }
+  if (first != MI_OK) {
+    set_error(msg);
+    if (g->bar) g->bar->reset();
+  }
+  return first;
+}
+
+int group_create(const mi_model_config& cfg, mi_ctx* facade) {
+  const int T = cfg.tp_degree;
+  MI_CHECK(T >= 2 && T <= kArMaxRanks, "in-process tensor parallelism: tp_degree must be 2..16");
+  int ndev = 0;
+  MI_HIP(hipGetDeviceCount(&ndev));
+  bool same = true, distinct = true;
+  for (int r = 0; r < T; ++r) {
+    MI_CHECK(cfg.tp_device_ids[r] >= 0 && cfg.tp_device_ids[r] < ndev, "tp_device_ids entry out of range");
+    if (cfg.tp_device_ids[r] != cfg.tp_device_ids[0]) same = false;
+    for (int q = 0; q < r; ++q)
+      if (cfg.tp_device_ids[q] == cfg.tp_device_ids[r]) distinct = false;
+  }
+  MI_CHECK(same || distinct, "tp_device_ids must be all distinct (one GPU per rank) or all equal (single-GPU loopback)");
+  mi_group* g = new mi_group();
+  g->T = T;
+  g->lockstep = same;
+  g->use_rccl = (!same && cfg.tp_transport == MI_TP_TRANSPORT_RCCL) ? 1 : 0;
+  g->bar = new HostBarrier(T);
+  g->ranks.assign(T, nullptr);
+  g->rc.assign(T, MI_OK);
+  g->err.assign(T, "");
+  g->counters.assign(T, nullptr);
+  facade->owned_group = g;
+  if (!same) {   // peer mappings, both directions
+    for (int r = 0; r < T; ++r) {
+      MI_HIP(hipSetDevice(cfg.tp_device_ids[r]));
+      for (int p = 0; p < T; ++p) {
+        if (p == r) continue;
+        int can = 0;
+        MI_HIP(hipDeviceCanAccessPeer(&can, cfg.tp_device_ids[r], cfg.tp_device_ids[p]));
+        MI_CHECK(can || g->use_rccl, "tp_device_ids: a pair of GPUs has no peer access (use tp_transport = RCCL)");
+        if (can) {
+          hipError_t pe = hipDeviceEnablePeerAccess(cfg.tp_device_ids[p], 0);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) MI_HIP(pe);
+          (void)hipGetLastError();
+        }
+      }
+    }
+  }
+  for (int r = 0; r < T; ++r) g->threads.emplace_back(rank_thread, g, r, cfg.tp_device_ids[r]);
+  // every shard is an ordinary context of rank r, created on its own thread / device
+  std::vector<mi_ctx*> made(T, nullptr);
+  int rc = group_run(g, [&](mi_ctx*, int r) -> int {
+    mi_model_config k = cfg;
+    k.tp_rank = r;
+    k.device_id = cfg.tp_device_ids[r];
+    if (g->lockstep) k.use_graphs = 0;   // host barriers sit between the exchange kernels
+    mi_ctx* c = nullptr;
+    int rc2 = mi_ctx_create(&k, &c);
+    if (rc2 != MI_OK) return rc2;
+    c->grp = g;
+    made[r] = c;
+    return MI_OK;
+  });
+  for (int r = 0; r < T; ++r) g->ranks[r] = made[r];
+  if (rc != MI_OK) return rc;
+  if (g->lockstep) {   // one stream for every shard: the order of the exchange kernels is the enqueue order
+    g->shared_stream = g->ranks[0]->stream;
+    for (int r = 1; r < T; ++r) {
+      hipStreamDestroy(g->ranks[r]->stream);
+      g->ranks[r]->stream = g->shared_stream;
+      g->ranks[r]->stream_owned = false;
+    }
+  }
+  if (g->use_rccl) {
+    std::vector<ncclComm_t> comms(T);
+    std::vector<int> devs(cfg.tp_device_ids, cfg.tp_device_ids + T);
+    ncclResult_t nr = ncclCommInitAll(comms.data(), T, devs.data());
+    if (nr != ncclSuccess) {
+      set_error(std::string("ncclCommInitAll: ") + ncclGetErrorString(nr));
+      return MI_ECOMM;
+    }
+    for (int r = 0; r < T; ++r) g->ranks[r]->comm = comms[r];
+  }
+  return MI_OK;
+}
+
+void group_destroy(mi_group* g) {
+  if (!g) return;
+  if (!g->threads.empty()) {
+    group_run(g, [&](mi_ctx* c, int r) -> int {
+      if (c) {
+        if (g->counters[r]) hipFree(g->counters[r]);
+        void* p[] = {g->peers.xbuf[r], g->peers.ybuf[r], g->peers.flag1[r], g->peers.flag2[r]};
+        for (void* q : p) if (q) hipFree(q);
+        mi_ctx_destroy(c);
+      }
+      return MI_OK;
+    });
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->stop = true;
+      g->cv_job.notify_all();
+    }
+    for (auto& t : g->threads) t.join();
+  }
+  delete g->bar;
+  delete g;
+}
+
+static int alloc_exchange_mem(void** p, size_t bytes) {
+  // uncached: a peer's loads must come from this GPU's memory, not from a cache line of an earlier epoch
+  hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    MI_HIP(hipMalloc(p, bytes));
+  }
+  return MI_OK;
+}
+
+int group_alloc_exchange(mi_ctx* c) {
+  mi_group* g = c->grp;
+  const int r = c->cfg.tp_rank, T = g->T;
+  if (!g->use_rccl) {
+    const size_t cap = (size_t)c->max_rows * c->H;
+    const size_t ycap = ((cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
+    void *xb = nullptr, *yb = nullptr, *f1 = nullptr, *f2 = nullptr, *ct = nullptr;
+    if (alloc_exchange_mem(&xb, 2 * cap * 4) != MI_OK) return MI_EHIP;   // two slots, fp32-sized (token generation sends fp32)
+    if (alloc_exchange_mem(&yb, 2 * ycap * 2) != MI_OK) return MI_EHIP;
+    const size_t fbytes = (size_t)T * kArMaxBlocks * 4;
+    if (alloc_exchange_mem(&f1, fbytes) != MI_OK) return MI_EHIP;
+    if (alloc_exchange_mem(&f2, fbytes) != MI_OK) return MI_EHIP;
+    MI_HIP(hipMalloc(&ct, AR_WORDS * 4));
+    MI_HIP(hipMemsetAsync(f1, 0, fbytes, c->stream));
+    MI_HIP(hipMemsetAsync(f2, 0, fbytes, c->stream));
+    MI_HIP(hipMemsetAsync(ct, 0, AR_WORDS * 4, c->stream));
+    MI_HIP(hipStreamSynchronize(c->stream));
+    g->peers.xbuf[r] = (uint16_t*)xb;
+    g->peers.ybuf[r] = (uint16_t*)yb;
+    g->peers.flag1[r] = (uint32_t*)f1;
+    g->peers.flag2[r] = (uint32_t*)f2;
+    g->counters[r] = (uint32_t*)ct;
+    g->cap = cap;
+    c->workspace_bytes += 8 * cap + 4 * ycap + 2 * fbytes;
+  }
+  // every rank's pointers are in the table before anyone launches an exchange
+  MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
+  return MI_OK;
+}
+
+int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
+  mi_group* g = c->grp;
+  const int T = g->T, r = c->cfg.tp_rank;
+  hipStream_t s = c->stream;
+  if (g->use_rccl) {
+    ncclResult_t nr = ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, c->comm, s);
+    if (nr != ncclSuccess) {
+      set_error(std::string("ncclAllReduce: ") + ncclGetErrorString(nr));
+      return MI_ECOMM;
+    }
+    return MI_OK;
+  }
+  MI_CHECK(count % 8 == 0 && count <= g->cap, "all-reduce: message not a multiple of 8 elements or larger than the exchange slot");
+  ArGeom ge{};
+  ge.T = T; ge.r = r; ge.chunks = (unsigned)(count / 8); ge.cap = g->cap;
+  ge.ycap = ((g->cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
+  const bool two_shot = count * 2 >= kArTwoShotBytes && T > 2;
+  uint32_t* ctr = g->counters[r];
+  // publish: one chunk per thread where the message allows it
+  ge.G = (int)std::min<unsigned>(kArMaxBlocks, std::max<unsigned>(1, ceil_div((int)ge.chunks, kArThreads)));
+  ge.cpw = (ge.chunks + ge.G - 1) / ge.G;
+  ge.pubG = ge.G;
+  if (two_shot) hipLaunchKernelGGL(ar_publish_kernel<false>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
+  else hipLaunchKernelGGL(ar_publish_kernel<true>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
+  if (g->lockstep) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");   // every rank's publish is in the stream
+  if (!two_shot) {
+    hipLaunchKernelGGL(ar_reduce_kernel<true>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
+  } else {
+    ArGeom g2 = ge;
+    g2.cps = (ge.chunks + T - 1) / T;
+    g2.G = (int)std::min<unsigned>(kArMaxBlocks, std::max<unsigned>(1, ceil_div((int)g2.cps, kArThreads)));
+    g2.cpw = (g2.cps + g2.G - 1) / g2.G;
+    hipLaunchKernelGGL(ar_reduce_scatter_kernel, dim3(g2.G), dim3(kArThreads), 0, s, buf, g->peers, g2, ctr);
+    if (g->lockstep) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
+    hipLaunchKernelGGL(ar_gather_kernel, dim3(g2.G), dim3(kArThreads), 0, s, buf, g->peers, g2, ctr);
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int group_check_errors(mi_ctx* c) {
+  mi_group* g = c->grp;
+  if (!g || g->use_rccl) return MI_OK;
+  uint32_t w = 0;
+  MI_HIP(hipMemcpy(&w, g->counters[c->cfg.tp_rank] + AR_ERROR, 4, hipMemcpyDeviceToHost));
+  if (w != 0) {
+    set_error("tensor-parallel exchange: a rank gave up waiting for a peer's flag (peer fault or P2P visibility problem)");
+    return MI_ECOMM;
+  }
+  return MI_OK;
+}
+
+}  // namespace mi
