@@ -3,24 +3,43 @@
 max_num_seqs=4 (BASELINE.json), on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 64 --warmup 8
+    python bench.py --gpus N ...                       (one process drives the N GPUs, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one token-generation pass of the hot path over one batch: B = max_num_seqs = 4
-sequences at context 1024 (BASELINE.md roofline row), all 32 layers + lm_head, through
+sequences at context 1024 (BASELINE.md roofline row), all layers + lm_head, through
 libmi355x_vllm.  The timed region is exactly K steps with every input resident in HBM
 (mi_replay_decode: hipGraph replays bracketed by HIP events on the library's stream, and by
-barrier + torch.cuda.synchronize on both sides); `value` = B * K / max-over-ranks time.  With
-N > 1 the model is tensor-parallel over the N GPUs (one process per GPU, RCCL all-reduce of the
-row-parallel partials): total work is fixed -> "scaling": "strong".
+barrier + torch.cuda.synchronize on both sides); `value` = B * K / max-over-ranks time.
 
-Also reported (same JSON line): p50 TTFT through the whole plugin path (scheduler -> runner ->
-library -> CPU sampler) per context-encoding bucket, the PCIe-inclusive decode rate through
-mi_forward, the roofline of the dominant kernel (the weight-streaming GEMV) and, at N = 1, the
-CPU oracle timed on the host cores over a bounded sample of the same workload.
+What the line says, key by key:
+  value / ms_per_step          the DEVICE step: the hot path replayed with resident inputs -- no
+                               scheduler, no H2D, no logits D2H, no sampler.  Kernel quality.
+  engine_decode_tokens_per_s   what a user of the plugin sees: scheduler -> runner -> library ->
+                               CPU sampler (the reference's parity path), 4 requests x 128 tokens.
+  engine_decode_tokens_per_s_on_device_sampling   the same loop with the on-device sampler.
+  ttft_p50_ms                  p50 time to first token through the whole plugin path, per
+                               context-encoding bucket, in the WEIGHT-ONLY mode (FP8 weights x bf16
+                               activations: what the reference's quantized linears compute -- the
+                               parity path).
+  ttft_p50_ms_fp8_activations  the fast mode (per-token FP8 activations on the MX-scaled MFMA) and
+  fp8_activation_first_token_agreement   how often its greedy first token equals the parity path's.
+  roofline                     the weight-streaming GEMV (dominant kernel): algorithmic weight bytes
+                               per launch / average launch duration.  The duration is measured live:
+                               the GEMV launches of a step replayed back to back in a graph of their
+                               own, HIP events around K such replays on the library's stream
+                               (launch-to-launch, as rocprofv3's kernel trace counts it).
+  cpu_baseline                 the CPU oracle (oracle/, test infrastructure) on the host cores.
+
+N > 1: tensor parallelism inside ONE process, the reference's process model (a single worker
+drives every core): the driver process owns one rank shard per GPU on threads inside the library.
+Launched under torch.distributed.run, local rank 0 is that driver and the other ranks only take
+part in the barriers and the max-over-ranks of the wall clock; launched directly with --gpus N it
+needs no launcher.  Total work is fixed -> "scaling": "strong".
 
 Weights are synthetic N(0, 0.02) (no checkpoints exist offline), generated on the device at the
-real Llama-3.1-8B shapes and quantized per-channel to OCP e4m3.
+real shapes and quantized per-channel.
 """
 
 from __future__ import annotations
@@ -36,12 +55,28 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LLAMA31_8B = dict(
-    architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=128256, hidden_size=4096,
-    intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
-    head_dim=128, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False,
-    rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
-                  "original_max_position_embeddings": 8192})
+LLAMA3_ROPE = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+               "original_max_position_embeddings": 8192}
+MODELS = {
+    "llama31_8b": dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=128256, hidden_size=4096,
+        intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+        head_dim=128, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False, rope_scaling=LLAMA3_ROPE),
+    "qwen25_7b": dict(
+        architectures=["Qwen2ForCausalLM"], model_type="qwen2", vocab_size=152064, hidden_size=3584,
+        intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+        head_dim=128, rms_norm_eps=1e-6, rope_theta=1000000.0, tie_word_embeddings=False, rope_scaling=None),
+    "llama33_70b": dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=128256, hidden_size=8192,
+        intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8,
+        head_dim=128, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False, rope_scaling=LLAMA3_ROPE),
+    # BASELINE config 1 (CPU plumbing): TinyLlama-1.1B dims, used by cpu_baseline only
+    "tinyllama_1b": dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=32000, hidden_size=2048,
+        intermediate_size=5632, num_hidden_layers=22, num_attention_heads=32, num_key_value_heads=4,
+        head_dim=64, rms_norm_eps=1e-5, rope_theta=10000.0, tie_word_embeddings=False, rope_scaling=None),
+}
+MODEL_LABEL = {"llama31_8b": "Llama-3.1-8B", "qwen25_7b": "Qwen2.5-7B", "llama33_70b": "Llama-3.3-70B"}
 BLOCK_SIZE, MAX_NUM_SEQS, MAX_MODEL_LEN, PA_NUM_BLOCKS = 32, 4, 2048, 4096
 BUCKETS = [256, 512, 1024, 2048]
 DECODE_CTX = 1024
@@ -59,24 +94,11 @@ def weight_bytes_per_step(hf, tp, bytes_per_param=1):
 
 
 def kv_bytes_per_step(hf, tp, B, ctx):
-    return B * ctx * 2 * (hf["num_key_value_heads"] / tp) * hf["head_dim"] * 2 * hf["num_hidden_layers"]
+    return B * ctx * 2 * max(hf["num_key_value_heads"] / tp, 1) * hf["head_dim"] * 2 * hf["num_hidden_layers"]
 
 
-def cpu_baseline(hf, B, ctx, layers=2, steps=4):
-    """The CPU oracle (test infrastructure, `oracle/`) timed on this box's host cores over a
-    bounded sample: `layers` of the 32 decoder layers + the lm_head, `steps` decode steps at
-    B x ctx; extrapolated linearly in the layer count."""
-    import torch
-    from oracle import DecoderConfig, PagedDecoderOracle
-    # a 1-GPU box grants 16 host cores however many the machine reports
-    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MI_BENCH_CPU_THREADS", 16)))
-    torch.set_num_threads(ncores)
-    cfg = DecoderConfig(num_layers=layers, hidden_size=hf["hidden_size"], num_heads=hf["num_attention_heads"],
-                        num_kv_heads=hf["num_key_value_heads"], head_dim=hf["head_dim"],
-                        intermediate_size=hf["intermediate_size"], vocab_size=hf["vocab_size"],
-                        rms_norm_eps=hf["rms_norm_eps"], rope_theta=hf["rope_theta"],
-                        rope_scaling=hf["rope_scaling"])
-    g = torch.Generator().manual_seed(1)
+# ---- CPU baseline (the oracle: test infrastructure, only ever the thing measured BESIDE the product) ----
+def _oracle_weights(torch, cfg, layers, g):
     H, hd = cfg.hidden_size, cfg.head_dim
 
     def mat(n, k):
@@ -94,30 +116,91 @@ def cpu_baseline(hf, B, ctx, layers=2, steps=4):
         w[p + "mlp.down_proj.weight"] = mat(H, cfg.intermediate_size)
         w[p + "input_layernorm.weight"] = torch.ones(H)
         w[p + "post_attention_layernorm.weight"] = torch.ones(H)
+    return w
+
+
+def _decoder_config(hf, layers):
+    from oracle import DecoderConfig
+    return DecoderConfig(num_layers=layers, hidden_size=hf["hidden_size"], num_heads=hf["num_attention_heads"],
+                         num_kv_heads=hf["num_key_value_heads"], head_dim=hf["head_dim"],
+                         intermediate_size=hf["intermediate_size"], vocab_size=hf["vocab_size"],
+                         rms_norm_eps=hf["rms_norm_eps"], rope_theta=hf["rope_theta"], rope_scaling=hf["rope_scaling"])
+
+
+def cpu_baseline(hf, B, ctx, layers=2, steps=3):
+    """The CPU oracle timed on this box's host cores over a BOUNDED sample of the workload:
+      * token generation at B x ctx and context encoding of the 256 bucket, over `layers` of the
+        model's decoder layers + lm_head, extrapolated linearly in the layer count;
+      * BASELINE config 1 in full: TinyLlama-1.1B dimensions (22 layers, fp32), 4 prompts of
+        6 / 9 / 7 / 140 tokens, greedy, 16 new tokens, prefix caching on -- prompts encoded one at
+        a time, then batched token generation, like the reference's scheduler."""
+    import torch
+    from oracle import PagedDecoderOracle
+    from tests.helpers import decode_inputs, prefill_inputs
+    # a 1-GPU box grants 16 host cores however many the machine reports
+    ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MI_BENCH_CPU_THREADS", 16)))
+    torch.set_num_threads(ncores)
+    g = torch.Generator().manual_seed(1)
+    cfg = _decoder_config(hf, layers)
+    w = _oracle_weights(torch, cfg, layers, g)
     mb = MAX_MODEL_LEN // BLOCK_SIZE
     oracle = PagedDecoderOracle(cfg, w, 1 + B * mb, BLOCK_SIZE, compute="fp32")
     oracle.kv.normal_(generator=g)
-    from tests.helpers import decode_inputs
     blocks = [[1 + b * mb + j for j in range(mb)] for b in range(B)]
-    inp = decode_inputs([1] * B, [ctx - 1] * B, blocks, BLOCK_SIZE, MAX_MODEL_LEN)
+    dec = decode_inputs([1] * B, [ctx - 1] * B, blocks, BLOCK_SIZE, MAX_MODEL_LEN)
+    pre = prefill_inputs(torch.randint(0, cfg.vocab_size, (256 - 17,), generator=g).tolist(), blocks[0], BLOCK_SIZE,
+                         MAX_MODEL_LEN, 0)
 
-    def timed(o, n):
+    def timed(o, inp, n):
         o.forward(**inp)
         t = time.perf_counter()
         for _ in range(n):
             o.forward(**inp)
         return (time.perf_counter() - t) / n
-    t_full = timed(oracle, steps)
-    # lm_head + embedding alone: the same oracle with zero layers
+    from oracle import DecoderConfig
     cfg0 = DecoderConfig(**{**cfg.__dict__, "num_layers": 0})
     o0 = PagedDecoderOracle(cfg0, {k: v for k, v in w.items() if "layers" not in k}, 2, BLOCK_SIZE, compute="fp32")
-    t_head = timed(o0, steps)
+    L = hf["num_hidden_layers"]
+    t_full, t_head = timed(oracle, dec, steps), timed(o0, dec, steps)
     t_layer = max(t_full - t_head, 0.0) / layers
-    t_step = t_layer * hf["num_hidden_layers"] + t_head
+    t_step = t_layer * L + t_head
+    p_full, p_head = timed(oracle, pre, 1), timed(o0, pre, 1)
+    p_layer = max(p_full - p_head, 0.0) / layers
+    ttft_256 = p_layer * L + p_head
+    del oracle, o0, w
+
+    # ---- config 1, in full ----
+    tl = MODELS["tinyllama_1b"]
+    tcfg = _decoder_config(tl, tl["num_hidden_layers"])
+    tw = _oracle_weights(torch, tcfg, tl["num_hidden_layers"], g)
+    tmb = 1024 // BLOCK_SIZE
+    to = PagedDecoderOracle(tcfg, tw, 1 + 4 * tmb, BLOCK_SIZE, compute="fp32")
+    prompts = [torch.randint(0, tcfg.vocab_size, (n,), generator=g).tolist() for n in (6, 9, 7, 140)]
+    tblocks = [[1 + b * tmb + j for j in range(tmb)] for b in range(4)]
+    t0 = time.perf_counter()
+    seqs, ttfts = [], []
+    for p, bl in zip(prompts, tblocks):
+        t1 = time.perf_counter()
+        lg = to.forward(**prefill_inputs(p, bl, BLOCK_SIZE, 1024, 0))
+        seqs.append(p + [int(lg.argmax())])
+        ttfts.append(time.perf_counter() - t1)
+    t_dec0 = time.perf_counter()
+    new_tokens = 16
+    for _ in range(new_tokens - 1):
+        lg = to.forward(**decode_inputs([s[-1] for s in seqs], [len(s) - 1 for s in seqs], tblocks, BLOCK_SIZE, 1024))
+        for s, row in zip(seqs, lg):
+            s.append(int(row.argmax()))
+    t_end = time.perf_counter()
+    config1 = {"workload": "TinyLlama-1.1B dims (22 layers, fp32), 4 prompts of 6/9/7/140 tokens, greedy, 16 new tokens, "
+                           "block_size 32, max_num_seqs 4: run in full",
+               "decode_tokens_per_s": round(4 * (new_tokens - 1) / (t_end - t_dec0), 2),
+               "ttft_ms": [round(x * 1e3, 1) for x in ttfts], "total_s": round(t_end - t0, 2)}
     return {"value": round(B / t_step, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": (f"oracle (torch CPU fp32) decode at B={B}, ctx={ctx}: {steps} steps over {layers} of "
-                       f"{hf['num_hidden_layers']} layers + lm_head, per-layer time extrapolated to 32 layers "
-                       f"({t_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head)")}
+            "sample": (f"oracle (torch CPU fp32) token generation at B={B}, ctx={ctx}: {steps} steps over {layers} of "
+                       f"{L} layers + lm_head, per-layer time extrapolated to {L} layers "
+                       f"({t_layer * 1e3:.1f} ms/layer, {t_head * 1e3:.1f} ms head); TTFT: one 239-token prompt "
+                       f"(bucket 256) over the same {layers} layers, extrapolated likewise"),
+            "ttft_ms_bucket_256": round(ttft_256 * 1e3, 1), "config1_cpu": config1}
 
 
 def main():
@@ -125,84 +208,131 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "qwen25_7b", "llama33_70b"])
     ap.add_argument("--ttft-prompts", type=int, default=32, help="prompts per context-encoding bucket (p50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--weight-dtype", default="f8e4m3", choices=["f8e4m3", "int8", "bf16"])
-    ap.add_argument("--bf16-prefill-activations", action="store_true",
-                    help="weight-only quantization in the context-encoding GEMMs too (default: FP8 x FP8)")
+    ap.add_argument("--weight-dtype", default=None, choices=["f8e4m3", "int8", "bf16"],
+                    help="default: f8e4m3 (int8 for qwen25_7b)")
+    ap.add_argument("--tp-transport", default="p2p", choices=["p2p", "rccl"])
+    ap.add_argument("--tp-loopback", action="store_true",
+                    help="dev: place every rank shard of --gpus N on GPU 0 (functional check of the TP path on one GPU)")
     args = ap.parse_args()
+    wd = args.weight_dtype or ("int8" if args.model == "qwen25_7b" else "f8e4m3")
+    HF = MODELS[args.model]
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    assert world in (1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    tp = args.gpus
     if world > 1:
-        # host-side control plane only (unique-id broadcast, barriers, max-over-ranks of the wall
-        # clock): gloo.  The data-path collectives are RCCL calls inside the library, on its own
-        # communicator and stream; a second (torch) RCCL communicator per process would add nothing.
+        # host-side control plane only (barriers, max-over-ranks of the wall clock): gloo
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    driver = rank == 0                      # the ONE process that owns the tensor-parallel group
 
-    def barrier_sync():
+    def host_barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+
+    def finish(line):
+        if driver:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    if not driver:
+        # the driver's context drives every GPU; this rank only meets it at the barriers of the timed region
+        for _ in range(2):
+            host_barrier()
+        tt = torch.zeros(1, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return finish(None)
+
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if args.tp_loopback:
+        os.environ["MI355X_TP_LOOPBACK"] = "1"
+    elif tp > 1:
+        assert torch.cuda.device_count() >= tp, (
+            f"--gpus {tp}: this process sees {torch.cuda.device_count()} GPUs; the tensor-parallel group lives in ONE "
+            "process and needs all of them visible")
+    torch.cuda.set_device(0)
+
+    def barrier_sync():
+        host_barrier()
+        for d in range(1 if args.tp_loopback else tp):
+            torch.cuda.synchronize(d)
 
     from vllm_neuron_amd._vllm_compat import SamplingParams
     from vllm_neuron_amd.engine import MI355XEngine
-    hf = SimpleNamespace(**LLAMA31_8B)
+    hf = SimpleNamespace(**HF)
     override = {"synthetic_weights": {"seed": 1, "std": 0.02}, "context_encoding_buckets": BUCKETS,
-                "pa_num_blocks": PA_NUM_BLOCKS}
-    if args.weight_dtype != "bf16":
-        override.update(quantized=True, quantization_dtype=args.weight_dtype,
-                        quantization_type="per_channel_symmetric")
-    if args.weight_dtype == "f8e4m3" and not args.bf16_prefill_activations:
-        # context-encoding GEMMs: per-token FP8 activations on the MX-scaled MFMA (FP8 x FP8)
-        override["prefill_fp8_activations"] = True
+                "pa_num_blocks": PA_NUM_BLOCKS, "tp_transport": args.tp_transport}
+    if wd != "bf16":
+        override.update(quantized=True, quantization_dtype=wd, quantization_type="per_channel_symmetric")
+
+    def make_engine(fp8_activations):
+        o = dict(override)
+        if fp8_activations:
+            o["prefill_fp8_activations"] = True   # context-encoding GEMMs: per-token FP8 activations, MX-scaled MFMA
+        return MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
+                            num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True,
+                            tensor_parallel_size=tp, override_mi355x_config=o)
     t0 = time.perf_counter()
-    eng = MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
-                       num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True,
-                       tensor_parallel_size=world, override_mi355x_config=override, rank=rank,
-                       local_rank=local_rank)
+    eng = make_engine(False)                # the parity path: weight-only quantization everywhere
     native = eng.worker.model_runner.model.model
     init_s = time.perf_counter() - t0
 
     # ---- p50 TTFT per bucket, through scheduler -> runner -> library -> CPU sampler ----------
-    g = torch.Generator().manual_seed(0)
-
     def ttft_sweep(engine, tag):
-        res = {}
+        g = torch.Generator().manual_seed(0)            # the same prompts for every mode
+        res, first = {}, {}
         for bucket in BUCKETS:
-            samples = []
+            samples, toks = [], []
             for _ in range(args.ttft_prompts + 1):           # first one is warm-up
                 prompt = torch.randint(0, hf.vocab_size, (bucket - 17,), generator=g).tolist()
                 out = engine.generate([prompt], SamplingParams(temperature=0.0, max_tokens=1))[0]
                 samples.append(out.ttft_s * 1e3)
+                toks.append(out.token_ids[0])
             res[str(bucket)] = round(statistics.median(samples[1:]), 3)
-            if rank == 0:
-                print(f"[bench] ttft {tag} bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
-        return res
-    ttft = ttft_sweep(eng, "fp8xfp8" if override.get("prefill_fp8_activations") else "weight-only")
-    # the other context-encoding numerics mode, for the record: FP8 weights x bf16 activations on the
-    # bf16 MFMA (what the reference's weight-only quantized linears compute); one more engine
-    ttft_wo = None
-    if override.get("prefill_fp8_activations") and world == 1:
-        o2 = dict(override)
-        o2["prefill_fp8_activations"] = False
-        eng2 = MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
-                            num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True,
-                            tensor_parallel_size=world, override_mi355x_config=o2, rank=rank, local_rank=local_rank)
-        ttft_wo = ttft_sweep(eng2, "weight-only")
+            first[str(bucket)] = toks[1:]
+            print(f"[bench] ttft {tag} bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
+        return res, first
+    ttft, first_wo = ttft_sweep(eng, "weight-only")
+    ttft_a8, agreement = None, None
+    if wd == "f8e4m3":
+        eng2 = make_engine(True)
+        ttft_a8, first_a8 = ttft_sweep(eng2, "fp8xfp8")
+        agreement = {b: round(sum(x == y for x, y in zip(first_wo[b], first_a8[b])) / max(len(first_wo[b]), 1), 3)
+                     for b in first_wo}
         eng2.worker.model_runner.model.model.close()
         del eng2
 
-    # ---- the whole serving loop (scheduler -> runner -> library -> sampler), for the record: 4
-    #      requests of 900 prompt tokens decoding 128 tokens each, first with the CPU sampler (the
-    #      parity path: [B, V] fp32 logits cross PCIe every step), then with on-device sampling
-    #      (B ids cross).  Rates are of the decode phase; not the headline `value`.
+    # ---- prefix caching (BASELINE config 4: sequences sharing a 512-token prefix) ----------------
+    prefix_ttft = None
+    if args.model == "qwen25_7b":
+        g = torch.Generator().manual_seed(7)
+        prefix_ttft = {}
+        for suf in (64, 128, 256):
+            miss, hit = [], []
+            for rep in range(9):
+                prefix = torch.randint(0, hf.vocab_size, (512,), generator=g).tolist()
+                mk = lambda: prefix + torch.randint(0, hf.vocab_size, (suf,), generator=g).tolist()   # noqa: E731
+                a = eng.generate([mk()], SamplingParams(temperature=0.0, max_tokens=1))[0]            # encodes the prefix
+                b = eng.generate([mk()], SamplingParams(temperature=0.0, max_tokens=1))[0]            # 16 cached blocks
+                assert a.num_cached_tokens == 0 and b.num_cached_tokens == 512, (a.num_cached_tokens, b.num_cached_tokens)
+                miss.append(a.ttft_s * 1e3)
+                hit.append(b.ttft_s * 1e3)
+            prefix_ttft[str(suf)] = {"miss_ms": round(statistics.median(miss[1:]), 3),
+                                     "hit_512_ms": round(statistics.median(hit[1:]), 3)}
+
+    # ---- the whole serving loop (scheduler -> runner -> library -> sampler): 4 requests of 900
+    #      prompt tokens decoding 128 tokens each, first with the CPU sampler (the parity path:
+    #      [B, V] fp32 logits cross PCIe every step), then with on-device sampling (B ids cross).
+    g = torch.Generator().manual_seed(3)
+
     def engine_decode_rate():
         prompts = [torch.randint(0, hf.vocab_size, (900,), generator=g).tolist() for _ in range(MAX_NUM_SEQS)]
         t_ = time.perf_counter()
@@ -211,10 +341,10 @@ def main():
         ntok = sum(len(o.token_ids) for o in outs)
         first = max(o.ttft_s for o in outs)
         return round((ntok - len(outs)) / (dt - first), 1)
-    engine_rates = {"cpu_sampling": engine_decode_rate()}
+    engine_cpu = engine_decode_rate()
     model_adapter = eng.worker.model_runner.model
     model_adapter.mi355x_config.on_device_sampling_config = {"dynamic": True, "deterministic": False}
-    engine_rates["on_device_sampling"] = engine_decode_rate()
+    engine_dev = engine_decode_rate()
     model_adapter.mi355x_config.on_device_sampling_config = None
 
     # ---- decode at other context lengths (ctx 256 / 1024 / 2040), device-resident ---
@@ -232,7 +362,7 @@ def main():
         n_c = max(args.steps // 2, 8)
         by_ctx[str(ctx_len)] = round(MAX_NUM_SEQS * n_c / (native.replay_decode(n_c) * 1e-3), 1)
 
-    # ---- decode: B sequences at context DECODE_CTX ------------------------------------------
+    # ---- decode: B sequences at context DECODE_CTX: the timed region ----------------------------
     inp = decode_inputs(toks, [DECODE_CTX - 1] * MAX_NUM_SEQS, blocks, BLOCK_SIZE, MAX_MODEL_LEN)
     for _ in range(2):
         native.forward(**inp)                            # captures the graph, leaves inputs resident
@@ -240,7 +370,8 @@ def main():
     barrier_sync()
     t = time.perf_counter()
     dev_ms = native.replay_decode(args.steps)            # exactly K timed steps
-    torch.cuda.synchronize()
+    for d in range(1 if args.tp_loopback else tp):
+        torch.cuda.synchronize(d)
     wall = time.perf_counter() - t
     barrier_sync()
     if world > 1:
@@ -251,67 +382,81 @@ def main():
     value = MAX_NUM_SEQS * args.steps / wall
 
     # PCIe-inclusive rate: the same step through mi_forward (ids H2D, [B, V] fp32 logits D2H)
-    barrier_sync()
     t = time.perf_counter()
     for _ in range(args.steps):
         native.forward(**inp)
     e2e = (time.perf_counter() - t) / args.steps
 
-    # ---- roofline of the dominant kernel (weight-streaming GEMV), HIP events per launch --------
-    native.profile_enable(True)
-    for _ in range(4):
+    # ---- roofline of the dominant kernel (weight-streaming GEMV) ----------------------------------
+    bpp = 2 if wd == "bf16" else 1
+    step_bytes = weight_bytes_per_step(HF, tp, bpp) + kv_bytes_per_step(HF, tp, MAX_NUM_SEQS, DECODE_CTX)
+    roofline = None
+    if tp == 1:
+        # launches and algorithmic bytes of the class from one eager, event-timed step ...
+        native.profile_enable(True)
         native.forward(**inp)
-    prof = native.profile_read()
-    native.profile_enable(False)
-    gemv_ms, gemv_n = prof["ms"]["gemv"], prof["launches"]["gemv"]
-    achieved = prof["gemv_weight_bytes"] / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else 0.0
-    step_bytes = weight_bytes_per_step(LLAMA31_8B, world, 2 if args.weight_dtype == "bf16" else 1) + kv_bytes_per_step(LLAMA31_8B, world, MAX_NUM_SEQS, DECODE_CTX)
-    # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
-    # gfx950-corrected; tests/pmc_summary.py) -- counters cannot be read from inside the process
-    traffic, traffic_src = None, None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemv_traffic.json")
-    if world == 1 and args.weight_dtype == "f8e4m3" and os.path.exists(tf):
-        with open(tf) as fh:
-            traffic = json.load(fh)["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)"
-    roofline = {"bound": "hbm", "kernel": "mi::gemv_kernel (all projections + lm_head of a step)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": round(prof["gemv_weight_bytes"] / max(gemv_n, 1)),
-                "launches_per_step": gemv_n // 4, "avg_launch_us": round(gemv_ms * 1e3 / max(gemv_n, 1), 2),
-                "step_algorithmic_GB": round(step_bytes / 1e9, 3),
-                "step_frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        prof = native.profile_read()
+        native.profile_enable(False)
+        gemv_n, gemv_bytes = prof["launches"]["gemv"], prof["gemv_weight_bytes"]
+        # ... their duration from the GEMV launches of a step replayed alone, back to back, in their own graph
+        native.forward(**inp)
+        gemv_ms = native.replay_decode_classes(args.steps, ["gemv"]) / args.steps
+        native.forward(**inp)                               # the full graph again (and a meaningful state)
+        achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
+        # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
+        # gfx950-corrected; tests/pmc_summary.py) -- counters cannot be read from inside the process
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r02_gemv_traffic.json")
+        if args.model == "llama31_8b" and wd == "f8e4m3" and os.path.exists(tf):
+            with open(tf) as fh:
+                traffic = json.load(fh)["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r02_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE pass of this command, x2 gfx950 correction)"
+        roofline = {"bound": "hbm", "kernel": "mi::gemv_kernel / gemv_priv_kernel (all projections + lm_head of a step)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": round(gemv_bytes / max(gemv_n, 1)),
+                    "launches_per_step": gemv_n, "avg_launch_us": round(gemv_ms * 1e3 / max(gemv_n, 1), 2),
+                    "gemv_only_ms_per_step": round(gemv_ms, 4),
+                    "duration_source": "HIP events around graph replays of the step's GEMV launches alone (launch-to-launch)",
+                    "step_algorithmic_GB": round(step_bytes / 1e9, 3),
+                    "step_frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    else:
+        roofline = {"bound": "hbm", "kernel": "per-GPU step (weights / TP + KV / TP)", "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": None, "step_algorithmic_GB": round(step_bytes / 1e9, 3)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(LLAMA31_8B, MAX_NUM_SEQS, DECODE_CTX)
+    if tp == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(MODELS["llama31_8b"] if args.model != "qwen25_7b" else HF, MAX_NUM_SEQS, DECODE_CTX)
 
-    if rank == 0:
-        line = {
-            "metric": "decode tokens/sec (Llama-3.1-8B FP8, block_size=32, max_num_seqs=4); p50 TTFT in ttft_p50_ms",
-            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": {"f8e4m3": ("fp8_e4m3 weights; token generation x bf16 activations, context encoding x "
-                                 + ("bf16" if args.bf16_prefill_activations else "per-token fp8_e4m3")
-                                 + " activations; f32 accumulate"),
-                      "int8": "int8 weights x bf16 activations, f32 accumulate",
-                      "bf16": "bf16, f32 accumulate"}[args.weight_dtype],
-            "data": "synthetic (seeded N(0,0.02) weights at real shapes; random token ids)",
-            "config": {"workload": f"Llama-3.1-8B {args.weight_dtype} TP={world}: token generation B={MAX_NUM_SEQS} "
-                                   f"ctx={DECODE_CTX}, block_size={BLOCK_SIZE}, pa_num_blocks={PA_NUM_BLOCKS}, "
-                                   f"max_model_len={MAX_MODEL_LEN}, buckets={BUCKETS}",
-                       "parallelism": f"tp{world}", "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
-            "ttft_p50_ms": ttft, "ttft_p50_ms_bf16_activations": ttft_wo, "device_ms_per_step": round(dev_ms / args.steps, 4),
-            "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
-            "engine_decode_tokens_per_s": engine_rates,
-            "pcie_inclusive_tokens_per_s": round(MAX_NUM_SEQS / e2e, 2),
-            "init_s": round(init_s, 2), "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    label = MODEL_LABEL[args.model]
+    wname = {"f8e4m3": "FP8", "int8": "INT8", "bf16": "bf16"}[wd]
+    line = {
+        "metric": f"decode tokens/sec ({label} {wname}, block_size=32, max_num_seqs=4): device step with resident inputs; "
+                  "p50 TTFT in ttft_p50_ms; engine-level rate in engine_decode_tokens_per_s",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": tp, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": {"f8e4m3": "fp8_e4m3 weights x bf16 activations (weight-only quantization), f32 accumulate",
+                  "int8": "int8 weights x bf16 activations, f32 accumulate",
+                  "bf16": "bf16, f32 accumulate"}[wd],
+        "data": "synthetic (seeded N(0,0.02) weights at real shapes; random token ids)",
+        "config": {"workload": f"{label} {wd} TP={tp}: token generation B={MAX_NUM_SEQS} "
+                               f"ctx={DECODE_CTX}, block_size={BLOCK_SIZE}, pa_num_blocks={PA_NUM_BLOCKS}, "
+                               f"max_model_len={MAX_MODEL_LEN}, buckets={BUCKETS}",
+                   "parallelism": f"tp{tp}" + (" (all shards on GPU 0: functional check)" if args.tp_loopback else ""),
+                   "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
+        "engine_decode_tokens_per_s": engine_cpu,
+        "engine_decode_tokens_per_s_on_device_sampling": engine_dev,
+        "ttft_p50_ms": ttft, "ttft_mode": "weight-only quantization (the parity path)",
+        "ttft_p50_ms_fp8_activations": ttft_a8, "fp8_activation_first_token_agreement": agreement,
+        "prefix_cache_ttft_ms": prefix_ttft,
+        "device_ms_per_step": round(dev_ms / args.steps, 4),
+        "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
+        "pcie_inclusive_tokens_per_s": round(MAX_NUM_SEQS / e2e, 2),
+        "init_s": round(init_s, 2), "roofline": roofline, "cpu_baseline": cpu,
+    }
+    finish(line)
 
 
 if __name__ == "__main__":

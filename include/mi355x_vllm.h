@@ -146,6 +146,13 @@ int mi_forward_tokens(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_id
  * and a [B, V] fp32 D2H copy per step. */
 int mi_replay_decode(mi_ctx* ctx, int32_t steps, float* elapsed_ms);
 
+/* The same replay with only the kernel classes of `class_mask` (bit MI_K_*) launched: e.g.
+ * 1 << MI_K_GEMV replays the weight-streaming launches of a step back to back, in a graph of their
+ * own -- elapsed / (steps x launches) is the average launch duration of that kernel, boundary
+ * included, which is how rocprofv3's kernel trace counts it.  Timing only: the step's results are
+ * not meaningful.  Single-GPU contexts. */
+int mi_replay_decode_classes(mi_ctx* ctx, int32_t steps, uint32_t class_mask, float* elapsed_ms);
+
 typedef struct mi_kv_stats_t {
   int64_t kv_bytes, weight_bytes, workspace_bytes, device_free_bytes, device_total_bytes;
   int32_t num_blocks, block_size, num_kv_heads_local, head_dim, num_layers;

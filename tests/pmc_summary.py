@@ -13,13 +13,13 @@ d, out = sys.argv[1], sys.argv[2]
 f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1]
 per = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if r["Counter_Name"] != "FETCH_SIZE" or "gemv_kernel" not in r["Kernel_Name"]:
+    if r["Counter_Name"] != "FETCH_SIZE" or "gemv_" not in r["Kernel_Name"]:
         continue
     per[r["Kernel_Name"].split("(")[0].replace("void mi::", "")].append(float(r["Counter_Value"]))
 n = sum(len(v) for v in per.values())
 total = sum(sum(v) for v in per.values()) * 1024 * 2
 doc = {
-    "kernel": "mi::gemv_kernel (all projections + lm_head of the decode steps in the pass)",
+    "kernel": "mi::gemv_kernel / gemv_priv_kernel (all projections + lm_head of the decode steps in the pass)",
     "launches": n,
     "traffic_bytes_per_launch": round(total / n),
     "per_instantiation_median_bytes": {k: round(sorted(v)[len(v) // 2] * 2048) for k, v in per.items()},

@@ -122,3 +122,25 @@ def test_engine_random_sampling_with_seed():
     b = [o.token_ids for o in eng.generate(p, sp)]
     assert a == b and all(len(t) == 6 for t in a)
     eng.worker.model_runner.model.model.close()
+
+
+@pytest.mark.parametrize("name,tp", [("llama31_like", 2), ("tinyllama_like", 4)])
+def test_engine_tensor_parallel_in_one_process(name, tp, monkeypatch):
+    """MI355XEngine(tensor_parallel_size=N) in ONE process, as vLLM's uni executor runs the plugin
+    (reference platform.py:166-167): one worker, one library context that owns the N rank shards.
+    A gpurun box has one GPU, so the shards share it (MI355X_TP_LOOPBACK=1)."""
+    from vllm_neuron_amd._vllm_compat import SamplingParams
+    from vllm_neuron_amd.engine import MI355XEngine
+    monkeypatch.setenv("MI355X_TP_LOOPBACK", "1")
+    cfg = zoo_config(name)
+    eng = MI355XEngine(hf_like(name), max_model_len=256, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                       tensor_parallel_size=tp, override_mi355x_config={"state_dict": make_weights(cfg, 1)})
+    assert eng.worker.tp_device_ids == [0] * tp
+    prompts = make_prompts(cfg.vocab_size, 0)
+    outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12))
+    check_against_golden(name, outs)
+    # on-device sampling over the vocabulary-parallel logits gives the same greedy ids
+    eng.worker.model_runner.model.mi355x_config.on_device_sampling_config = {"dynamic": True}
+    again = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12))
+    assert [o.token_ids for o in again] == [o.token_ids for o in outs]
+    eng.worker.model_runner.model.model.close()

@@ -73,6 +73,7 @@ _SIGS = {
                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.c_void_p]),
     "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
+    "mi_replay_decode_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
     "mi_stream": (C.c_void_p, [C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -270,6 +271,16 @@ class NativeModel:
         (HIP events on the library's stream)."""
         ms = C.c_float()
         check(self.lib.mi_replay_decode(self._ctx, steps, C.byref(ms)))
+        return ms.value
+
+    def replay_decode_classes(self, steps: int, classes) -> float:
+        """Replay the last token-generation step with only the kernel classes named in `classes`
+        (K_CLASSES names) launched; -> elapsed ms.  Timing only."""
+        mask = 0
+        for name in classes:
+            mask |= 1 << K_CLASSES.index(name)
+        ms = C.c_float()
+        check(self.lib.mi_replay_decode_classes(self._ctx, steps, mask, C.byref(ms)))
         return ms.value
 
     def kv_stats(self) -> dict:

@@ -111,6 +111,7 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   e.scale = L.scale;
   e.bias = L.bias;
   if (gemv_fits(rows, L.K)) {
+    if (!c->runs(MI_K_GEMV)) return MI_OK;
     Scope sc(c, MI_K_GEMV);
     if (c->prof.on) c->prof.gemv_bytes += (double)L.bytes();
     return launch_gemv(L.view(), rows, pro, p, epi, e, c->stream);
@@ -189,7 +190,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
                int logits_row0) {
   const mi_model_config& k = c->cfg;
   hipStream_t s = c->stream;
-  {
+  if (c->runs(MI_K_OTHER)) {
     Scope sc(c, MI_K_OTHER);
     MI_TRY(launch_embed(c->d_ids, c->embed, rows, c->H, c->resid[0], s));
   }
@@ -213,7 +214,9 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       MI_TRY(run_linear(c, W.qkv, rows, PRO_NORM, p, EPI_QKV, e));
       if (have_partial) cur ^= 1;
     }
-    if (decode) {
+    if (decode && !c->runs(MI_K_ATTN_DECODE)) {
+      // (class-masked replay: see mi_replay_decode_classes)
+    } else if (decode) {
       Scope sc(c, MI_K_ATTN_DECODE);
       MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
                                 c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true));
@@ -457,7 +460,7 @@ float bf16_bits_to_f32(uint16_t h) {
 }
 
 int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
-  const int key = B * 65536 + MB;
+  const int key = (B * 65536 + MB) ^ (int)((c->class_mask & 0xff) << 24);
   // a caller-supplied transport runs on the host thread: never captured
   if (!c->cfg.use_graphs || c->prof.on || c->xport_allreduce) return run_layers(c, B, true, B, MB, 0, B, 0);
   auto it = c->graphs.find(key);
@@ -960,6 +963,16 @@ int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
   hipEventDestroy(a);
   hipEventDestroy(b);
   return prof_collect(c);
+}
+
+int mi_replay_decode_classes(mi_ctx* c, int32_t steps, uint32_t class_mask, float* elapsed_ms) {
+  MI_CHECK(c && c->finalized && elapsed_ms && class_mask != 0, "bad argument");
+  MI_CHECK(!c->owned_group && !c->collective(), "mi_replay_decode_classes: single-GPU contexts only");
+  c->class_mask = class_mask;
+  int rc = mi_replay_decode(c, 2, elapsed_ms);          // capture (eager pass + graph) and warm
+  if (rc == MI_OK) rc = mi_replay_decode(c, steps, elapsed_ms);
+  c->class_mask = 0xffffffffu;
+  return rc;
 }
 
 int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {

@@ -89,6 +89,10 @@ struct mi_ctx {
   std::map<int, hipGraphExec_t> graphs;  // token-generation graph per (B * 65536 + MB)
   int last_B = 0, last_MB = 0;           // shape of the last token-generation call (mi_replay_decode)
   Prof prof;
+  // kernel classes the token-generation step launches (mi_replay_decode_classes measures a step with
+  // some of them left out; the results of such a step are meaningless, its timing is the point)
+  uint32_t class_mask = 0xffffffffu;
+  bool runs(int cls) const { return (class_mask >> cls) & 1u; }
   ncclComm_t comm = nullptr;
   // caller-supplied collectives in place of RCCL (mi_tp_init_transport)
   mi_allreduce_fn xport_allreduce = nullptr;

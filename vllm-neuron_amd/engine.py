@@ -36,7 +36,7 @@ class RequestOutput:
 class MI355XEngine:
     def __init__(self, hf_config, model: str = "", *, max_model_len=2048, max_num_seqs=4, block_size=32,
                  num_gpu_blocks_override=None, enable_prefix_caching=True, tensor_parallel_size=1,
-                 dtype="bfloat16", override_mi355x_config: dict | None = None, seed=0, rank=0, local_rank=0):
+                 dtype="bfloat16", override_mi355x_config: dict | None = None, seed=0, local_rank=0):
         if HAVE_VLLM:  # pragma: no cover
             raise RuntimeError("vLLM is installed: use vllm.LLM(...) — the plugin registers itself")
         cfg = SimpleVllmConfig(
@@ -50,8 +50,10 @@ class MI355XEngine:
             additional_config={"override_mi355x_config": dict(override_mi355x_config or {})})
         MI355XPlatform.check_and_update_config(cfg)
         self.vllm_config = cfg
-        self.worker = MI355XWorker(cfg, local_rank=local_rank, rank=rank, distributed_init_method="",
-                                   is_driver_worker=True)  # every TP rank holds the full logits (all-gather) and samples identically
+        # ONE worker whatever tensor_parallel_size is (uni executor): the library context behind it
+        # drives every GPU of the tensor-parallel group
+        self.worker = MI355XWorker(cfg, local_rank=local_rank, rank=0, distributed_init_method="",
+                                   is_driver_worker=True)
         self.worker.init_device()
         self.worker.load_model()
         spec = self.worker.get_kv_cache_spec()["layer"]
@@ -92,8 +94,6 @@ class MI355XEngine:
     def step(self):
         sched_out = self.scheduler.schedule()
         runner_out = self.worker.execute_model(sched_out)
-        if runner_out is None:      # non-driver TP rank: mirror the driver's bookkeeping blindly
-            return sched_out, None
         now = time.perf_counter()
         for new_req in sched_out.scheduled_new_reqs:
             self.outputs[new_req.req_id].num_cached_tokens = new_req.num_computed_tokens

@@ -125,7 +125,8 @@ class MI355XPlatform(Platform):
         if parallel_config.worker_cls == "auto":
             parallel_config.worker_cls = WORKER_CLS
         if parallel_config.world_size > 1:
-            # one engine-side worker; the tensor-parallel ranks are this plugin's own processes
+            # one engine-side worker; the library context behind it drives every GPU of the
+            # tensor-parallel group (rank shards on threads of libmi355x_vllm), as NxDI does in the reference
             parallel_config.distributed_executor_backend = "uni"
 
         if native_scheduler:

@@ -15,6 +15,7 @@ working).  Extra keys understood here:
   synthetic_weights          {"seed","std"} random weights generated on the device (bench)
   state_dict                 dict[str, Tensor] in-memory HF-named weights (tests)
   use_graphs                 bool           hipGraph capture of token-generation steps
+  tp_transport               "p2p" | "rccl" exchange between the rank shards of tensor_parallel_size > 1
   prefill_fp8_activations    bool           context-encoding GEMMs on FP8 weights quantize their bf16
                                             inputs per token to e4m3 and run on the MX-scaled MFMA
 """
@@ -185,7 +186,11 @@ class MI355XCausalLM(MI355XModelBase):
         if quantized and (qdtype not in _QUANT_DTYPES or qtype not in _QUANT_TYPES):
             raise ValueError(f"unsupported quantization_dtype/type: {qdtype!r}/{qtype!r}")
         not_converted = cfg.get("modules_to_not_convert") or []
-        tp_rank = int(kwargs.get("tp_rank", 0))
+        tp_degree = int(cfg["tp_degree"])
+        tp_devices = list(kwargs.get("tp_device_ids") or [])
+        if tp_degree > 1 and len(tp_devices) != tp_degree:
+            raise RuntimeError(f"tp_degree {tp_degree} needs {tp_degree} device ids, got {tp_devices}")
+        from .._native import MI_TP_ALL_RANKS, MI_TP_TRANSPORT
         self.model = NativeModel(
             num_blocks=int(num_blocks), block_size=int(block_size),
             max_num_seqs=int(cfg["batch_size"]), max_model_len=int(max_model_len),
@@ -193,17 +198,15 @@ class MI355XCausalLM(MI355XModelBase):
             weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0,
             quant_type=_QUANT_TYPES[qtype] if quantized else 0,
             quantize_lm_head=int(quantized and not any("lm_head" in m for m in not_converted)),
-            tp_degree=int(cfg["tp_degree"]), tp_rank=tp_rank,
+            # every rank shard lives inside this one context (the reference's single-worker model,
+            # platform.py:166-167): one GPU and one library thread per shard
+            tp_degree=tp_degree, tp_rank=MI_TP_ALL_RANKS if tp_degree > 1 else 0,
+            tp_device_ids=tp_devices if tp_degree > 1 else [],
+            tp_transport=MI_TP_TRANSPORT[cfg.get("tp_transport", "p2p")],
             device_id=int(kwargs.get("device_id", 0)),
-            # collectives are launched eagerly for now: graphs only when a single GPU runs the step
-            use_graphs=int(cfg.get("use_graphs", int(cfg["tp_degree"]) == 1)),
+            use_graphs=int(cfg.get("use_graphs", 1)),
             prefill_fp8_activations=int(bool(cfg.get("prefill_fp8_activations", False))),
             **geo)
-        if cfg["tp_degree"] > 1:
-            uid = kwargs.get("tp_unique_id")
-            if uid is None:
-                raise RuntimeError("tp_degree > 1 needs the RCCL unique id broadcast by the worker")
-            self.model.tp_init(uid)
         synthetic = cfg.get("synthetic_weights")
         state_dict = cfg.get("state_dict")
         if synthetic is not None:

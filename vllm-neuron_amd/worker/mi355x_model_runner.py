@@ -72,7 +72,7 @@ class MI355XModelRunner:
     _SLOT_MAPPING_PAD = -1
     _BLOCK_TABLE_PAD = 0
 
-    def __init__(self, vllm_config, device, tp_rank: int = 0, device_id: int = 0, tp_unique_id=None):
+    def __init__(self, vllm_config, device, device_id: int = 0, tp_device_ids=None):
         self.vllm_config = vllm_config
         self.model_config = vllm_config.model_config
         self.cache_config = vllm_config.cache_config
@@ -84,7 +84,7 @@ class MI355XModelRunner:
         self.observability_config = vllm_config.observability_config
         self.device_config = vllm_config.device_config
         self.device = device
-        self.tp_rank, self.device_id, self.tp_unique_id = tp_rank, device_id, tp_unique_id
+        self.device_id, self.tp_device_ids = device_id, list(tp_device_ids or [device_id])
 
         self.pin_memory = False
         self.block_size = self.cache_config.block_size
@@ -122,7 +122,7 @@ class MI355XModelRunner:
             self.model_config, cache_config=self.cache_config, parallel_config=self.parallel_config,
             scheduler_config=self.scheduler_config, lora_serving_config=None,
             speculative_config=self.speculative_config, additional_config=self.vllm_config.additional_config,
-            tp_rank=self.tp_rank, device_id=self.device_id, tp_unique_id=self.tp_unique_id)
+            device_id=self.device_id, tp_device_ids=self.tp_device_ids)
         cfg = self.model.mi355x_config
         self.is_block_kv_layout = cfg.is_block_kv_layout
         self.is_prefix_caching = cfg.is_prefix_caching

@@ -2,13 +2,17 @@
 """vLLM worker for MI355X: lifecycle shim around the model runner, same method set as the
 reference worker (/root/reference/vllm_neuron/worker/neuron_worker.py:21-146).
 
-Tensor parallelism: the reference hides TP inside ONE worker process (NxDI drives all
-NeuronCores).  The idiomatic MI355X layout is one process per GPU, so a TP group is
-`tensor_parallel_size` copies of this worker, launched by torchrun / the bench harness with
-RANK / LOCAL_RANK / WORLD_SIZE set; they rendezvous through torch.distributed only to share the
-128-byte RCCL unique id, after which every collective (all-reduce of the row-parallel partials,
-all-gather of the vocab-sharded logits) runs inside libmi355x_vllm on its own stream.  Every
-rank executes the same SchedulerOutput; rank 0 is the driver whose output vLLM sees.
+Tensor parallelism: exactly the reference's process model.  The platform forces vLLM's "uni"
+executor (platform.py), so there is ONE worker whatever `tensor_parallel_size` says, and the model
+object behind it drives every device (reference: NxDI inside the single NeuronWorker,
+neuron_worker.py:106-121, loader.py:752-753).  Here the library context is created with
+`tp_rank = MI_TP_ALL_RANKS`: it owns one rank shard per GPU, each on a host thread of its own inside
+libmi355x_vllm, exchanging through the library's all-reduce over peer-mapped memory (xGMI).  The
+worker hands the same SchedulerOutput to that one context; nothing here knows about ranks.
+
+Which GPUs: `tensor_parallel_size` devices starting at `local_rank` (normally 0 .. T-1), or the
+comma-separated list in MI355X_TP_DEVICES.  When fewer GPUs are visible than ranks and
+MI355X_TP_LOOPBACK=1, every shard is placed on the first device (tests on a one-GPU box).
 """
 
 import logging
@@ -36,21 +40,37 @@ class MI355XWorker(WorkerBase):
                 pass
         self.device = self.device_config.device
         self.tp_size = self.parallel_config.tensor_parallel_size
-        self.tp_rank = int(os.environ.get("RANK", rank)) % max(self.tp_size, 1) if self.tp_size > 1 else 0
-        self.device_id = int(os.environ.get("LOCAL_RANK", local_rank)) if self.tp_size > 1 else max(local_rank, 0)
+        self.device_id = max(local_rank, 0)
+        self.tp_device_ids = self._pick_tp_devices() if self.tp_size > 1 else [self.device_id]
         self.model_runner = None
 
-    def get_mi355x_model_runner(self, vllm_config, device, tp_unique_id=None):
+    def _pick_tp_devices(self) -> list:
+        """One GPU per rank shard (see the module docstring)."""
+        env = os.environ.get("MI355X_TP_DEVICES")
+        if env:
+            ids = [int(x) for x in env.split(",") if x.strip() != ""]
+            if len(ids) != self.tp_size:
+                raise ValueError(f"MI355X_TP_DEVICES lists {len(ids)} devices, tensor_parallel_size is {self.tp_size}")
+            return ids
+        visible = torch.cuda.device_count()
+        if visible >= self.device_id + self.tp_size:
+            return list(range(self.device_id, self.device_id + self.tp_size))
+        if os.environ.get("MI355X_TP_LOOPBACK") == "1":
+            return [self.device_id] * self.tp_size
+        raise RuntimeError(
+            f"tensor_parallel_size={self.tp_size} needs {self.tp_size} GPUs from device {self.device_id}, "
+            f"{visible} visible (set MI355X_TP_DEVICES, or MI355X_TP_LOOPBACK=1 to place every shard on one GPU)")
+
+    def get_mi355x_model_runner(self, vllm_config, device):
         from .mi355x_model_runner import MI355XModelRunner
-        return MI355XModelRunner(vllm_config=vllm_config, device=device, tp_rank=self.tp_rank,
-                                 device_id=self.device_id, tp_unique_id=tp_unique_id)
+        return MI355XModelRunner(vllm_config=vllm_config, device=device, device_id=self.device_id,
+                                 tp_device_ids=self.tp_device_ids)
 
     def init_device(self) -> None:
         self.init_distributed_environment()
         self._bound_host_threads()
         set_random_seed(self.model_config.seed)
-        uid = self._exchange_tp_unique_id() if self.tp_size > 1 else None
-        self.model_runner = self.get_mi355x_model_runner(self.vllm_config, self.device, uid)
+        self.model_runner = self.get_mi355x_model_runner(self.vllm_config, self.device)
 
     def _bound_host_threads(self) -> None:
         """Keep torch's CPU pool (the sampler's argmax / top-k over [B, vocab]) inside this
@@ -68,26 +88,11 @@ class MI355XWorker(WorkerBase):
                 share = min(share, max(1, int(quota) // int(period)))
         except (OSError, ValueError):
             pass
-        share = max(1, share // max(1, self.tp_size))
         want = min(share, 8)
         if torch.get_num_threads() > want:
             logger.info("bounding torch CPU threads %d -> %d (cpu share %d)", torch.get_num_threads(),
                         want, share)
             torch.set_num_threads(want)
-
-    def _exchange_tp_unique_id(self) -> bytes:
-        """Rank 0 asks RCCL for a unique id; torch.distributed carries the 128 bytes."""
-        import torch.distributed as dist
-        from .._native import check, load_library
-        import ctypes
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo", rank=self.tp_rank, world_size=self.tp_size)
-        buf = ctypes.create_string_buffer(128)
-        if self.tp_rank == 0:
-            check(load_library().mi_tp_unique_id(buf))
-        obj = [buf.raw]
-        dist.broadcast_object_list(obj, src=0)
-        return obj[0]
 
     def determine_available_memory(self):
         """Free device memory after the weights are resident (the reference asks the Neuron
