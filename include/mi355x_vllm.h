@@ -156,8 +156,17 @@ int mi_replay_decode_classes(mi_ctx* ctx, int32_t steps, uint32_t class_mask, fl
 typedef struct mi_kv_stats_t {
   int64_t kv_bytes, weight_bytes, workspace_bytes, device_free_bytes, device_total_bytes;
   int32_t num_blocks, block_size, num_kv_heads_local, head_dim, num_layers;
+  /* token-generation block tables are device-resident: rows re-sent because the caller's row
+   * changed (new request, block appended) vs rows found unchanged since the previous step */
+  int64_t block_table_rows_sent, block_table_rows_kept;
 } mi_kv_stats_t;
 int mi_kv_stats(mi_ctx* ctx, mi_kv_stats_t* out);
+
+/* The pinned host buffer [max_num_seqs][vocab_size] fp32 the logits land in.  Passing it as
+ * mi_forward's logits_out skips the final host copy: the caller reads the logits in place, valid
+ * until the next call on this context.  NULL for tensor-parallel contexts (their shards fill the
+ * caller's rows directly) and before mi_finalize. */
+float* mi_logits_buffer(mi_ctx* ctx);
 
 /* hipStream_t the context launches on (for event timing by the caller). */
 void* mi_stream(mi_ctx* ctx);

@@ -15,7 +15,7 @@ BS, MAXLEN, NSEQ, NB = 32, 2048, 4, 4097
 MB = MAXLEN // BS
 m = NativeModel(**geo, num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
                 weight_dtype=MI_W[wd], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
-                tp_degree=1, tp_rank=0, device_id=0, use_graphs=1, ctx_buckets=[256, 512, 1024, 2048],
+                tp_degree=1, tp_rank=0, device_id=0, use_graphs=int(os.environ.get('MI355X_GRAPHS', '1')), ctx_buckets=[256, 512, 1024, 2048],
                 prefill_fp8_activations=0)
 m.init_synthetic_weights(1, 0.02)
 m.finalize()
@@ -26,4 +26,14 @@ for _ in range(3):
     m.forward(**inp)
 m.replay_decode(20)
 best = min(m.replay_decode(steps) / steps for _ in range(3))
+import time
+t = time.perf_counter()
+for _ in range(200):
+    m.forward(**inp)
+fw = (time.perf_counter() - t) / 200 * 1e3
+t = time.perf_counter()
+for _ in range(200):
+    m.forward_tokens(**inp)
+ft = (time.perf_counter() - t) / 200 * 1e3
+print(f"forward loop {fw:.4f} ms/call, forward_tokens loop {ft:.4f} ms/call (graphs={os.environ.get('MI355X_GRAPHS', '1')})")
 print(f"{wd} ctx={ctx}: {best:.4f} ms/step -> {NSEQ / best * 1e3:.0f} tok/s  (env PRIV={os.environ.get('MI355X_GEMV_PRIV', '1')})", flush=True)

@@ -399,6 +399,38 @@ def test_decode_input_contract_and_block_append():              # runner.py:765-
     assert r.requests["a"].block_ids == ([20, 21],)
 
 
+def test_incremental_decode_inputs_equal_the_rebuilt_ones():
+    """The persistent token-generation inputs (block-table rows rewritten only when a request moves
+    into the row or a block is appended) are, field for field, what the reference's per-step rebuild
+    produces (runner.py:765-832, 887-917) -- over requests joining, finishing and changing rows."""
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", list(range(31)), [5])]))
+    r.execute_model(sched_out([new_req("b", list(range(40)), [6, 7])]))
+    r.execute_model(sched_out([new_req("c", list(range(70)), [9, 10, 11])]))
+
+    def step(ids, new_blocks, computed, finished=()):
+        cached = CachedRequestData(req_ids=ids, resumed_from_preemption=[False] * len(ids), new_token_ids=[[]] * len(ids),
+                                   new_block_ids=new_blocks, num_computed_tokens=computed)
+        so = sched_out(cached=cached, finished=list(finished))
+        r._update_states(so)
+        fast = r._prepare_decode_inputs_incremental(so)
+        data, is_prefill = r._prepare_continuous_batching_inputs(so)
+        slow = r._finalize_continuous_batching_inputs(data, is_prefill)
+        assert not is_prefill and fast.request_ids == slow.request_ids
+        for f in ("input_tokens", "position_ids", "input_block_ids", "slot_mapping", "block_tables",
+                  "full_context_lens", "computed_context_lens"):
+            assert torch.equal(getattr(fast, f), getattr(slow, f)), f
+        # feed the sampled token back like execute_model does
+        for rid in ids:
+            r.requests[rid].output_token_ids.append(7)
+
+    step(["a", "b", "c"], [([8],), None, None], [31, 40, 70])            # a crosses into a second block
+    step(["a", "b", "c"], [None, None, None], [32, 41, 71])              # nothing changes: rows are kept
+    step(["a", "c"], [None, None], [33, 72], finished=["b"])             # c moves up a row
+    r.execute_model(sched_out([new_req("d", list(range(10)), [12])]))    # a prefill in between
+    step(["a", "c", "d"], [None, None, None], [34, 73, 10])              # d takes a fresh row
+
+
 def test_finished_requests_free_seq_ids():                      # tests :683-718, :1020-1049
     r = make_runner()
     r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))

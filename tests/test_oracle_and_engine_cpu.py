@@ -114,7 +114,7 @@ class OracleBackedModel:
         self.adapter.is_reorder_needed = False
         self.adapter.native_block_size = block_size
         self.adapter.model = type("F", (), {"forward": staticmethod(
-            lambda ids, pos, seq, bt, sm, full, comp: self.oracle.forward(ids, pos, seq, bt, sm, full, comp))})()
+            lambda ids, pos, seq, bt, sm, full, comp, alias_ok=False: self.oracle.forward(ids, pos, seq, bt, sm, full, comp))})()
 
     def __call__(self, **kw):
         self.adapter.is_reorder_needed = self.is_reorder_needed

@@ -49,7 +49,8 @@ class MiKvStats(C.Structure):
     _fields_ = [("kv_bytes", C.c_int64), ("weight_bytes", C.c_int64), ("workspace_bytes", C.c_int64),
                 ("device_free_bytes", C.c_int64), ("device_total_bytes", C.c_int64),
                 ("num_blocks", C.c_int32), ("block_size", C.c_int32),
-                ("num_kv_heads_local", C.c_int32), ("head_dim", C.c_int32), ("num_layers", C.c_int32)]
+                ("num_kv_heads_local", C.c_int32), ("head_dim", C.c_int32), ("num_layers", C.c_int32),
+                ("block_table_rows_sent", C.c_int64), ("block_table_rows_kept", C.c_int64)]
 
 
 # include/mi355x_vllm.h: mi_allreduce_fn / mi_allgather_fn
@@ -76,6 +77,7 @@ _SIGS = {
     "mi_replay_decode_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
     "mi_stream": (C.c_void_p, [C.c_void_p]),
+    "mi_logits_buffer": (C.c_void_p, [C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                   C.POINTER(C.c_double)]),
@@ -163,6 +165,7 @@ class NativeModel:
             c.ctx_buckets[i] = int(b)
         self.cfg = c
         self.vocab_size = c.vocab_size
+        self._logits_view = None
         self._ctx = C.c_void_p()
         check(self.lib.mi_ctx_create(C.byref(c), C.byref(self._ctx)))
 
@@ -225,18 +228,35 @@ class NativeModel:
     def finalize(self) -> None:
         check(self.lib.mi_finalize(self._ctx))
 
+    def _pinned_logits(self):
+        """Zero-copy view [max_num_seqs, V] of the library's pinned logits buffer (None for
+        tensor-parallel contexts)."""
+        if self._logits_view is None:
+            ptr = self.lib.mi_logits_buffer(self._ctx)
+            if not ptr:
+                self._logits_view = False
+            else:
+                n = self.cfg.max_num_seqs * self.vocab_size
+                buf = (C.c_float * n).from_address(ptr)
+                self._logits_view = torch.frombuffer(buf, dtype=torch.float32).reshape(self.cfg.max_num_seqs,
+                                                                                       self.vocab_size)
+        return self._logits_view if self._logits_view is not False else None
+
     def forward(self, input_ids, position_ids, seq_ids, block_table, slot_mapping,
-                full_context_lens, computed_context_lens) -> "torch.Tensor":
+                full_context_lens, computed_context_lens, alias_ok: bool = False) -> "torch.Tensor":
         """CPU int64 tensors in (the reference's ModelInputForNeuron fields), fp32 CPU
-        last-token logits [B, V] out."""
+        last-token logits [B, V] out.  alias_ok: the result may be a view of the library's pinned
+        buffer, overwritten by the next call (the runner samples from it at once: saves a 2 MB
+        host copy and an allocation per step)."""
         def i64(t):
-            return t.to(torch.int64).contiguous()
+            return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.to(torch.int64).contiguous()
         ids, pos = i64(input_ids), i64(position_ids)
         B, S = ids.shape
         bt, sm = i64(block_table).reshape(B, -1), i64(slot_mapping).reshape(B, -1)
         full, comp = i64(full_context_lens).reshape(-1), i64(computed_context_lens).reshape(-1)
         seq = i64(seq_ids).reshape(-1) if seq_ids is not None else torch.zeros(B, dtype=torch.int64)
-        out = torch.empty(B, self.vocab_size, dtype=torch.float32)
+        pinned = self._pinned_logits() if alias_ok else None
+        out = pinned[:B] if pinned is not None else torch.empty(B, self.vocab_size, dtype=torch.float32)
         check(self.lib.mi_forward(self._ctx, B, S, ids.data_ptr(), pos.data_ptr(), seq.data_ptr(),
                                   bt.data_ptr(), bt.shape[1], sm.data_ptr(), sm.shape[1],
                                   full.data_ptr(), comp.data_ptr(), out.data_ptr()))

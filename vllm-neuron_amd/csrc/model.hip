@@ -307,7 +307,7 @@ int fetch_logits(mi_ctx* c, int nrows, float* out) {
     g_ht.lap(3);
     MI_HIP(hipStreamSynchronize(c->stream));
     g_ht.lap(4);
-    memcpy(out, c->h_logits, (size_t)nrows * V * 4);
+    if (out != c->h_logits) memcpy(out, c->h_logits, (size_t)nrows * V * 4);   // mi_logits_buffer callers read in place
     g_ht.lap(5);
     return MI_OK;
   }
@@ -587,9 +587,9 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_inputs, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws};
+                  c->attn_scratch, c->d_inputs, c->d_dec, c->d_dec_bt, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws};
   for (void* p : ptrs) hipFree(p);
-  void* hptrs[] = {c->h_inputs, c->h_sparams, c->h_tokens, c->h_logits};
+  void* hptrs[] = {c->h_inputs, c->h_dec, c->h_dec_bt, c->h_sparams, c->h_tokens, c->h_logits};
   for (void* p : hptrs) if (p) hipHostFree(p);
   if (c->stream_owned) hipStreamDestroy(c->stream);
   delete c;
@@ -775,6 +775,17 @@ int mi_finalize(mi_ctx* c) {
     c->d_bt = d[0]; c->d_ctx = d[1]; c->d_ids = d[2]; c->d_pos = d[3]; c->d_slots = d[4];
     c->h_bt = h[0]; c->h_ctx = h[1]; c->h_ids = h[2]; c->h_pos = h[3]; c->h_slots = h[4];
   }
+  {   // token-generation inputs: small per-step block + device-resident block tables
+    const size_t ms = (size_t)k.max_num_seqs;
+    MI_TRY(dmalloc(&c->d_dec, 4 * ms, ws));
+    MI_TRY(dmalloc(&c->d_dec_bt, nbt, ws));
+    MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_dec), 4 * ms * 4, hipHostMallocDefault));
+    MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_dec_bt), nbt * 4, hipHostMallocDefault));
+    memset(c->h_dec, 0, 4 * ms * 4);
+    memset(c->h_dec_bt, 0, nbt * 4);
+    MI_HIP(hipMemsetAsync(c->d_dec_bt, 0, nbt * 4, s));
+    c->bt_checked.assign(ms, 0);
+  }
   MI_TRY(dmalloc(&c->d_sparams, (size_t)k.max_num_seqs * 3, ws));
   MI_TRY(dmalloc(&c->d_tokens, (size_t)k.max_num_seqs, ws));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_sparams), (size_t)k.max_num_seqs * 3 * 4, hipHostMallocDefault));
@@ -784,6 +795,20 @@ int mi_finalize(mi_ctx* c) {
   if (c->grp) MI_TRY(group_alloc_exchange(c));
   c->finalized = true;
   return MI_OK;
+}
+
+// current views of the step inputs (run_layers and a captured graph read these pointers)
+static void set_input_views(mi_ctx* c, bool decode_step) {
+  const mi_model_config& k = c->cfg;
+  const size_t ms = (size_t)k.max_num_seqs, R = (size_t)c->max_rows, nbt = ms * c->MB_cap;
+  if (decode_step) {
+    c->d_ctx = c->d_dec; c->d_ids = c->d_dec + ms; c->d_pos = c->d_dec + 2 * ms; c->d_slots = c->d_dec + 3 * ms;
+    c->h_ctx = c->h_dec; c->h_ids = c->h_dec + ms; c->h_pos = c->h_dec + 2 * ms; c->h_slots = c->h_dec + 3 * ms;
+    c->d_bt = c->d_dec_bt; c->h_bt = c->h_dec_bt;
+  } else {
+    c->d_bt = c->d_inputs; c->d_ctx = c->d_inputs + nbt; c->d_ids = c->d_ctx + ms; c->d_pos = c->d_ids + R; c->d_slots = c->d_pos + R;
+    c->h_bt = c->h_inputs; c->h_ctx = c->h_inputs + nbt; c->h_ids = c->h_ctx + ms; c->h_pos = c->h_ids + R; c->h_slots = c->h_pos + R;
+  }
 }
 
 // logits_out != null: the reference's CPU-sampling contract (fp32 logits of the last token of every
@@ -860,16 +885,37 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
     }
     return MI_OK;
   };
-  auto push_inputs = [&]() -> int {   // the whole (25 KiB) input block in one copy
-    MI_HIP(hipMemcpyAsync(c->d_inputs, c->h_inputs, c->inputs_elems * 4, hipMemcpyHostToDevice, s));
-    return MI_OK;
-  };
+  auto use_inputs = [&](bool decode_step) { set_input_views(c, decode_step); };
 
   if (S == 1) {  // ---- token generation -------------------------------------------------
     g_ht.start();
+    use_inputs(true);
+    if (c->bt_shadow_MB != MB) {   // another table width: nothing on the device can be reused
+      c->bt_shadow.assign((size_t)k.max_num_seqs * MB, INT64_MIN);
+      c->bt_shadow_MB = MB;
+      std::fill(c->bt_checked.begin(), c->bt_checked.end(), 0);
+    }
+    int row_lo = B, row_hi = -1;   // rows whose device copy is stale
     for (int b = 0; b < B; ++b) {
       const int full = (int)full_context_lens[b];
-      MI_TRY(check_row(b, full, 1));
+      MI_CHECK(full >= 1 && full <= k.max_model_len, "full_context_lens out of range");
+      const int need = ceil_div(full, bs);
+      MI_CHECK(need <= MB, "block_table narrower than the context");
+      const int64_t* row = block_table + (size_t)b * MB;
+      int64_t* shadow = c->bt_shadow.data() + (size_t)b * MB;
+      if (memcmp(row, shadow, (size_t)MB * 8) != 0) {   // new request in this row / block appended: re-send the row
+        memcpy(shadow, row, (size_t)MB * 8);
+        for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)row[j];
+        c->bt_checked[b] = 0;
+        row_lo = std::min(row_lo, b);
+        row_hi = std::max(row_hi, b);
+        c->bt_rows_sent += 1;
+      } else {
+        c->bt_rows_kept += 1;
+      }
+      for (int j = c->bt_checked[b]; j < need; ++j)   // only the entries that became live
+        MI_CHECK(row[j] >= 0 && row[j] < k.num_blocks, "block_table entry out of range inside the live context");
+      c->bt_checked[b] = std::max(c->bt_checked[b], need);
       const int64_t pos = position_ids[b], slot = slot_mapping[(size_t)b * SM];
       MI_CHECK(pos >= 0 && pos < k.max_model_len, "position out of range");
       MI_CHECK(input_ids[b] >= 0 && input_ids[b] < V, "token id out of range");
@@ -878,8 +924,14 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
       c->h_pos[b] = (int32_t)pos;
       c->h_slots[b] = (int32_t)slot;
       c->h_ctx[b] = full;
-      for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)block_table[(size_t)b * MB + j];
     }
+    auto push_inputs = [&]() -> int {   // 4 x max_num_seqs ints, + the table rows that changed
+      MI_HIP(hipMemcpyAsync(c->d_dec, c->h_dec, (size_t)k.max_num_seqs * 16, hipMemcpyHostToDevice, s));
+      if (row_hi >= row_lo)
+        MI_HIP(hipMemcpyAsync(c->d_dec_bt + (size_t)row_lo * MB, c->h_dec_bt + (size_t)row_lo * MB,
+                              (size_t)(row_hi - row_lo + 1) * MB * 4, hipMemcpyHostToDevice, s));
+      return MI_OK;
+    };
     g_ht.lap(0);
     MI_TRY(push_inputs());
     g_ht.lap(1);
@@ -895,6 +947,11 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
 
   // ---- context encoding: one sequence at a time (the reference schedules ctx_batch_size 1,
   //      scheduler.py:116; loader.py:754-755) ------------------------------------------------
+  use_inputs(false);
+  auto push_inputs = [&]() -> int {   // the whole context-encoding input block in one copy
+    MI_HIP(hipMemcpyAsync(c->d_inputs, c->h_inputs, c->inputs_elems * 4, hipMemcpyHostToDevice, s));
+    return MI_OK;
+  };
   for (int b = 0; b < B; ++b) {
     const int full = (int)full_context_lens[b], comp = (int)computed_context_lens[b];
     const int n_new = full - comp;
@@ -952,6 +1009,7 @@ int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
   MI_CHECK(c->last_B > 0, "mi_replay_decode needs a preceding token-generation mi_forward");
   MI_CHECK(steps >= 1, "steps must be >= 1");
   MI_HIP(hipSetDevice(c->cfg.device_id));
+  set_input_views(c, true);
   hipEvent_t a, b;
   MI_HIP(hipEventCreate(&a));
   MI_HIP(hipEventCreate(&b));
@@ -987,7 +1045,13 @@ int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {
   o->device_free_bytes = (int64_t)fr; o->device_total_bytes = (int64_t)tot;
   o->num_blocks = c->cfg.num_blocks; o->block_size = c->cfg.block_size;
   o->num_kv_heads_local = c->nkv_l; o->head_dim = c->hd; o->num_layers = c->cfg.num_layers;
+  o->block_table_rows_sent = c->bt_rows_sent; o->block_table_rows_kept = c->bt_rows_kept;
   return MI_OK;
+}
+
+float* mi_logits_buffer(mi_ctx* c) {
+  if (!c || c->owned_group || c->collective() || !c->finalized) return nullptr;
+  return c->h_logits;
 }
 
 void* mi_stream(mi_ctx* c) {

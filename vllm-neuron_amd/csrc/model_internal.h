@@ -77,9 +77,21 @@ struct mi_ctx {
   // step inputs
   int32_t *d_ids = nullptr, *d_pos = nullptr, *d_slots = nullptr, *d_bt = nullptr, *d_ctx = nullptr;
   int32_t *h_ids = nullptr, *h_pos = nullptr, *h_slots = nullptr, *h_bt = nullptr, *h_ctx = nullptr;
-  // the five input arrays above are slices of ONE device block / ONE pinned block: one H2D per call
-  int32_t *d_inputs = nullptr, *h_inputs = nullptr;
+  // d_* / h_* above are the CURRENT views: context encoding uses slices of one block (one H2D per
+  // call: [block table row][ids][positions][slots]); token generation uses a second, small block
+  // [context lengths][ids][positions][slots] (one H2D of 4 x max_num_seqs ints per step) and block
+  // tables that STAY on the device: a row is re-sent only when the caller's row differs from the
+  // host shadow of what the device holds (a new request in the row, a block appended), and only
+  // the entries that became live since the last call are validated (the reference
+  // rebuilds and re-validates every table every step, runner.py:798-832, 887-917).
+  int32_t *d_inputs = nullptr, *h_inputs = nullptr;      // context-encoding block
   size_t inputs_elems = 0;
+  int32_t *d_dec = nullptr, *h_dec = nullptr;            // token-generation block: [ctx][ids][pos][slots], max_num_seqs each
+  int32_t *d_dec_bt = nullptr, *h_dec_bt = nullptr;      // resident block tables [max_num_seqs][MB of the last call]
+  std::vector<int64_t> bt_shadow;                        // the caller's rows the device tables were made from
+  std::vector<int> bt_checked;                           // per row: leading entries validated so far
+  int bt_shadow_MB = 0;
+  long bt_rows_sent = 0, bt_rows_kept = 0;               // statistics (mi_kv_stats)
   float* h_logits = nullptr;
   // on-device sampling: (top_k, top_p, temperature) rows and the sampled ids
   float *d_sparams = nullptr, *h_sparams = nullptr;

@@ -139,8 +139,10 @@ class MI355XCausalLM(MI355XModelBase):
                                                    sampling_params=inputs.get("sampling_params"),
                                                    seed=(self._sample_seed << 32) + self._sample_calls)
                 return restore(tokens)
+            # the runner samples from the logits before the next call: they may alias the library's
+            # pinned buffer (no 2 MB host copy / allocation per step)
             logits = self.model.forward(ids, inputs["position_ids"], seq_ids, block_table, slot_mapping,
-                                        inputs["full_context_lens"], computed)
+                                        inputs["full_context_lens"], computed, alias_ok=True)
             return restore(logits)
 
     def _batch_line_addressing(self, seq_ids, position_ids, full_context_lens, computed, S):

@@ -106,6 +106,7 @@ class MI355XModelRunner:
         self.vllm_req_to_seq_id_mapping: Dict[str, int] = {}
         self.free_seq_ids = set(range(self.max_num_reqs))
         self._draft_token_ids = None
+        self._decode_state = None        # persistent token-generation inputs (_prepare_decode_inputs_incremental)
         self.cpu_sampler = Sampler()
         self._kv_ready = False
 
@@ -277,8 +278,60 @@ class MI355XModelRunner:
     def _prepare_model_input(self, scheduler_output) -> ModelInputForMI355X:
         if self.is_chunked_prefill:
             raise NotImplementedError("chunked prefill inputs are not implemented on MI355X")
+        if self.is_prefix_caching and not scheduler_output.scheduled_new_reqs:
+            return self._prepare_decode_inputs_incremental(scheduler_output)
         data, is_prefill = self._prepare_continuous_batching_inputs(scheduler_output)
         return self._finalize_continuous_batching_inputs(data, is_prefill)
+
+    def _prepare_decode_inputs_incremental(self, scheduler_output) -> ModelInputForMI355X:
+        """Token-generation inputs without rebuilding what did not change.  Same
+        record, same values as `_process_cached_request_*` + `_finalize_*` produce; the padded
+        block-table rows persist across steps in one [max_num_seqs, MB] tensor -- a row is rewritten
+        only when another request takes it or a block is appended (the reference pads, copies and
+        stacks every table every step: runner.py:798-832, 887-917) -- and the library in turn keeps
+        the tables on the device and re-sends only rows that changed."""
+        cached = scheduler_output.scheduled_cached_reqs
+        req_ids = cached.req_ids
+        n = len(req_ids)
+        st = self._decode_state
+        mb = self.scheduler_config.max_model_len // self.cache_config.block_size
+        bs = self.cache_config.block_size
+        cfg = self.model.mi355x_config
+        pad = -1 if (cfg.attn_tkg_nki_kernel_enabled or cfg.attn_block_tkg_nki_kernel_enabled) else self._BLOCK_TABLE_PAD
+        if st is None or st["pad"] != pad:
+            st = self._decode_state = {"pad": pad, "rows": [None] * self.max_num_reqs, "nblk": [0] * self.max_num_reqs,
+                                       "bt": torch.full((self.max_num_reqs, mb), pad, dtype=torch.long)}
+        bt, rows, nblk = st["bt"], st["rows"], st["nblk"]
+        tokens, positions, seq_ids, slots = [], [], [], []
+        for i, req_id in enumerate(req_ids):
+            assert req_id in self.vllm_req_to_seq_id_mapping, (
+                "The request ID for the current decode request is not found in request to sequence ID mapping")
+            state = self.requests[req_id]
+            block_table = state.block_ids[0]
+            position = len(state.prompt_token_ids) + len(state.output_token_ids) - 1
+            if rows[i] != req_id:                    # another request moved into this row
+                bt[i].fill_(pad)
+                bt[i, :len(block_table)] = torch.as_tensor(block_table, dtype=torch.long)
+                rows[i], nblk[i] = req_id, len(block_table)
+            elif nblk[i] != len(block_table):        # blocks appended (or replaced after a preemption)
+                if len(block_table) < nblk[i]:
+                    bt[i, len(block_table):nblk[i]] = pad
+                bt[i, :len(block_table)] = torch.as_tensor(block_table, dtype=torch.long)
+                nblk[i] = len(block_table)
+            tokens.append(state.output_token_ids[-1])
+            positions.append(position)
+            seq_ids.append(self.vllm_req_to_seq_id_mapping[req_id])
+            slots.append(block_table[position // bs] * bs + position % bs)
+        for i in range(n, self.max_num_reqs):
+            rows[i] = None
+        pos_t = torch.tensor(positions, dtype=torch.long).reshape(n, 1)
+        input_tokens = torch.tensor(tokens, dtype=torch.long).reshape(n, 1)
+        return ModelInputForMI355X(
+            request_ids=list(req_ids), input_tokens=input_tokens, position_ids=pos_t,
+            input_block_ids=torch.tensor(seq_ids, dtype=torch.long),
+            slot_mapping=torch.tensor(slots, dtype=torch.long).reshape(n, 1), block_tables=bt[:n],
+            full_context_lens=pos_t + 1, computed_context_lens=pos_t, prefill_completion_state=None,
+            sampling_params=self._sampling_params_if_used(input_tokens), multi_modal_kwargs=None, adapter_ids=None)
 
     def _prepare_continuous_batching_inputs(self, scheduler_output) -> Tuple[IntermediateInputData, bool]:
         """New requests are prefills, cached requests are decodes; the scheduler never mixes
@@ -391,15 +444,16 @@ class MI355XModelRunner:
             request_ids=data.request_ids, input_tokens=input_tokens, position_ids=position_ids,
             input_block_ids=input_block_ids, slot_mapping=slot_mapping, block_tables=block_tables,
             full_context_lens=full_context_lens, computed_context_lens=computed_context_lens,
-            prefill_completion_state=None, sampling_params=self.get_mi355x_sampling_params(input_tokens),
+            prefill_completion_state=None, sampling_params=self._sampling_params_if_used(input_tokens),
             multi_modal_kwargs=data.multi_modal_kwargs, adapter_ids=None)
 
     # ---- sampling ---------------------------------------------------------------------------
     def _sample(self, hidden_states: torch.Tensor, model_input: ModelInputForMI355X):
         # rows come back in model_input.request_ids order; the sampler wants input_batch order
-        order = {rid: i for i, rid in enumerate(model_input.request_ids)}
-        reorder = torch.tensor([order[rid] for rid in self.input_batch.req_ids], dtype=torch.long)
-        hidden_states = hidden_states[reorder]
+        if list(model_input.request_ids) != list(self.input_batch.req_ids):
+            order = {rid: i for i, rid in enumerate(model_input.request_ids)}
+            reorder = torch.tensor([order[rid] for rid in self.input_batch.req_ids], dtype=torch.long)
+            hidden_states = hidden_states[reorder]     # (a [B, V] copy: only when the orders differ)
         try:
             if self.model.mi355x_config.on_device_sampling_config is None:
                 return self._cpu_sample(hidden_states, model_input)
@@ -407,6 +461,13 @@ class MI355XModelRunner:
         except Exception as e:
             logger.error("Sampling failed for requests %s: %s", model_input.request_ids, e)
             raise RuntimeError(f"Sampling operation failed: {str(e)}") from e
+
+    def _sampling_params_if_used(self, input_ids: torch.Tensor):
+        """The (top_k, top_p, temperature) rows only feed the on-device sampler; the CPU-sampling
+        path (where the reference passes them along unused) skips building them every step."""
+        if self.model.mi355x_config.on_device_sampling_config is None:
+            return None
+        return self.get_mi355x_sampling_params(input_ids)
 
     def get_mi355x_sampling_params(self, input_ids: torch.Tensor) -> torch.Tensor:
         """Per-request (top_k, top_p, temperature) rows, packed like the reference's
