@@ -140,6 +140,21 @@ int mi_forward_tokens(mi_ctx* ctx, int32_t B, int32_t S, const int64_t* input_id
                       const int64_t* full_context_lens, const int64_t* computed_context_lens,
                       const float* sampling_params, uint64_t seed, int64_t* tokens_out);
 
+/* Chunked prefill (the reference's path under vLLM's native scheduler: runner.py:938-1051,
+ * loader.py:357-361): ONE ragged batch of `total` tokens = the concatenated chunks of n_req
+ * requests -- request i contributes tokens computed_context_lens[i] .. full_context_lens[i] - 1
+ * (a prompt chunk, or the single next token of a request that is generating).  input_ids,
+ * position_ids, slot_mapping: [total] in request order; block_table [n_req, MB].  Every token's
+ * K/V is written through slot_mapping, each request attends to its own blocks, the projections run
+ * once over all rows.  logits_out [n_req, vocab_size] = logits of each request's LAST scheduled
+ * token (the caller ignores rows whose prompt is not complete: prefill_completion_state);
+ * or tokens_out [n_req] with sampling_params as in mi_forward_tokens.  total may not exceed the
+ * largest context-encoding bucket (pass max_num_batched_tokens as a bucket). */
+int mi_forward_chunked(mi_ctx* ctx, int32_t n_req, int32_t total, const int64_t* input_ids,
+                       const int64_t* position_ids, const int64_t* slot_mapping, const int64_t* block_table,
+                       int32_t MB, const int64_t* full_context_lens, const int64_t* computed_context_lens,
+                       float* logits_out, const float* sampling_params, uint64_t seed, int64_t* tokens_out);
+
 /* Replay the LAST token-generation call `steps` times with its inputs left resident in HBM
  * (no host round trip in between) and return the elapsed time measured with HIP events on the
  * context's stream.  For benchmarking the hot path itself: mi_forward adds one small H2D copy

@@ -73,6 +73,8 @@ _SIGS = {
     "mi_forward_tokens": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mi_forward_chunked": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "mi_replay_decode_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
@@ -284,6 +286,28 @@ class NativeModel:
                                          full.data_ptr(), comp.data_ptr(),
                                          sp.data_ptr() if sp is not None else None, seed & (2 ** 64 - 1),
                                          out.data_ptr()))
+        return out
+
+    def forward_chunked(self, input_ids, position_ids, slot_mapping, block_table, full_context_lens,
+                        computed_context_lens, sampling_params=None, seed: int = 0, tokens: bool = False):
+        """Chunked prefill: one ragged token batch (reference runner.py:1000-1051).  input_ids,
+        position_ids, slot_mapping: flat [total]; block_table [n, MB]; the context lengths [n].
+        -> fp32 logits [n, V] of every request's last scheduled token, or sampled ids [n] (tokens=True)."""
+        def i64(t):
+            return t.to(torch.int64).contiguous()
+        ids, pos, sm = i64(input_ids).reshape(-1), i64(position_ids).reshape(-1), i64(slot_mapping).reshape(-1)
+        full, comp = i64(full_context_lens).reshape(-1), i64(computed_context_lens).reshape(-1)
+        n = full.numel()
+        bt = i64(block_table).reshape(n, -1)
+        sp = None
+        if tokens and sampling_params is not None:
+            sp = sampling_params.to(torch.float32).contiguous()
+        out = torch.empty(n, dtype=torch.int64) if tokens else torch.empty(n, self.vocab_size, dtype=torch.float32)
+        check(self.lib.mi_forward_chunked(self._ctx, n, ids.numel(), ids.data_ptr(), pos.data_ptr(), sm.data_ptr(),
+                                          bt.data_ptr(), bt.shape[1], full.data_ptr(), comp.data_ptr(),
+                                          None if tokens else out.data_ptr(),
+                                          sp.data_ptr() if sp is not None else None, seed & (2 ** 64 - 1),
+                                          out.data_ptr() if tokens else None))
         return out
 
     def replay_decode(self, steps: int) -> float:

@@ -485,8 +485,10 @@ else:
 
     class Scheduler:
         """Minimal stand-in for vllm.v1.core.sched.scheduler.Scheduler: FCFS, running requests
-        first (one token each), then waiting requests (whole prompt minus the cached prefix),
-        bounded by max_num_seqs / max_num_batched_tokens / free KV blocks."""
+        first (their next token, or the rest of a partly encoded prompt), then waiting requests
+        (the prompt minus the cached prefix), bounded by max_num_seqs / max_num_batched_tokens /
+        free KV blocks.  With scheduler_config.chunked_prefill_enabled a prompt that does not fit
+        the step's token budget is encoded in chunks (vLLM's native behaviour); otherwise it waits."""
 
         def __init__(self, vllm_config, kv_cache_config=None, structured_output_manager=None,
                      include_finished_set=False, log_stats=False, **_):
@@ -497,6 +499,7 @@ else:
             self.max_num_scheduled_tokens = self.scheduler_config.max_num_batched_tokens
             self.max_model_len = self.scheduler_config.max_model_len
             self.block_size = self.cache_config.block_size
+            self.chunked_prefill = bool(getattr(self.scheduler_config, "chunked_prefill_enabled", False))
             num_blocks = kv_cache_config.num_blocks if kv_cache_config else self.cache_config.num_gpu_blocks
             self.block_pool = _BlockPool(num_blocks, self.block_size,
                                          bool(self.cache_config.enable_prefix_caching))
@@ -524,7 +527,10 @@ else:
             for req in list(self.running):
                 if budget <= 0:
                     break
-                need = self._blocks_needed(req, req.num_tokens)
+                n_tok = req.num_tokens - req.num_computed_tokens
+                if self.chunked_prefill:
+                    n_tok = min(n_tok, budget)           # the next chunk of a long prompt
+                need = self._blocks_needed(req, req.num_computed_tokens + n_tok)
                 new_blocks = self.block_pool.allocate(need) if need > 0 else []
                 if new_blocks is None:
                     break                      # out of KV blocks: leave the rest unscheduled
@@ -534,16 +540,18 @@ else:
                 cached.new_token_ids.append([])
                 cached.new_block_ids.append((new_blocks,) if new_blocks else None)
                 cached.num_computed_tokens.append(req.num_computed_tokens)
-                num_sched[req.request_id] = req.num_tokens - req.num_computed_tokens
-                budget -= num_sched[req.request_id]
+                num_sched[req.request_id] = n_tok
+                budget -= n_tok
             while self.waiting and budget > 0 and len(self.running) < self.max_num_running_reqs:
                 req = self.waiting[0]
                 hits = self.block_pool.lookup(req.all_token_ids)
                 n_cached = len(hits) * self.block_size
                 n_new = req.num_tokens - n_cached
                 if n_new > budget:
-                    break
-                need = -(-req.num_tokens // self.block_size) - len(hits)
+                    if not self.chunked_prefill:
+                        break
+                    n_new = budget                       # first chunk; the rest follows as a running request
+                need = -(-(n_cached + n_new) // self.block_size) - len(hits)
                 self.block_pool.touch(hits)
                 fresh = self.block_pool.allocate(need)
                 if fresh is None:

@@ -9,6 +9,8 @@ int launch_norm_rows(const float* resid_in, const float* partial, float* resid_o
 // K-step-major image [H / 128][T][128 B] + row_scale[T]
 int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
                          int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s);
+// dst[i, :] = src[rows[i], :]   (fp32 rows of H elements, H % 4 == 0)
+int launch_gather_rows(const float* src, const int32_t* rows, int n, int H, float* dst, hipStream_t s);
 int launch_f32_to_bf16(const float* in, uint16_t* out, size_t n, hipStream_t s);
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t tensor_id, float std, hipStream_t s);
 int launch_fill_f32(float* out, size_t n, float v, hipStream_t s);

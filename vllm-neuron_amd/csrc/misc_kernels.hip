@@ -54,6 +54,19 @@ int launch_embed(const int32_t* ids, const uint16_t* table, int T, int H, float*
   return MI_OK;
 }
 
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows, int H,
+                                   float* __restrict__ dst) {
+  const float4* from = reinterpret_cast<const float4*>(src + (size_t)rows[blockIdx.x] * H);
+  float4* to = reinterpret_cast<float4*>(dst + (size_t)blockIdx.x * H);
+  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) to[i] = from[i];
+}
+int launch_gather_rows(const float* src, const int32_t* rows, int n, int H, float* dst, hipStream_t s) {
+  MI_CHECK(H % 4 == 0 && n >= 1, "gather_rows: H % 4 == 0 required");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, s, src, rows, H, dst);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 // h = resid_in (+ partial) -> resid_out (optional); y = bf16(rmsnorm(h) * gain)   (reference K2)
 // FP8: instead of the bf16 row, emit what rowquant_fp8_kernel would make of it -- the row rounded
 // to bf16, then e4m3 with the per-token scale amax / 448 -- as the K-step-major image

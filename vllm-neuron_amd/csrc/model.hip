@@ -186,8 +186,15 @@ int all_reduce_partial(mi_ctx* c, int rows) {
 // The decoder stack over `rows` token rows whose ids/positions/slots are already in
 // d_ids/d_pos/d_slots.  decode: rows = B sequences (block tables d_bt [B, MB], lengths d_ctx).
 // prefill: rows = new tokens of ONE sequence at positions q_pos0.. (block table d_bt[0, :]).
+// segs != null: a RAGGED context-encoding batch (chunked prefill, reference runner.py:938-1051):
+// the rows are the concatenated chunks of nseg requests; request i owns rows [row0, row0 + n) at
+// positions pos0.. and block-table row i.  The projections see one [rows, K] matrix (the weights
+// cross the chip once for all requests); attention runs per request; the logits are those of
+// each request's last row (gathered through d_ctx, which holds the last-row indices).
+struct Seg { int row0, n, pos0; };
+
 int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int logits_rows,
-               int logits_row0) {
+               int logits_row0, const Seg* segs = nullptr, int nseg = 0) {
   const mi_model_config& k = c->cfg;
   hipStream_t s = c->stream;
   if (c->runs(MI_K_OTHER)) {
@@ -220,6 +227,12 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       Scope sc(c, MI_K_ATTN_DECODE);
       MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
                                 c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true));
+    } else if (segs) {
+      Scope sc(c, MI_K_ATTN_PREFILL);
+      for (int i = 0; i < nseg; ++i)
+        MI_TRY(launch_attn_prefill(c->qbuf + (size_t)segs[i].row0 * c->q_dim, segs[i].n, segs[i].pos0, kpool, vpool,
+                                   k.block_size, c->d_bt + (size_t)i * MB, c->nh_l, c->nkv_l, c->hd,
+                                   c->attn_out + (size_t)segs[i].row0 * c->q_dim, s));
     } else {
       Scope sc(c, MI_K_ATTN_PREFILL);
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
@@ -274,6 +287,16 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     ProArgs p{};
     p.resid_in = c->resid[cur] + (size_t)logits_row0 * c->H;
     p.partial = have_partial ? c->partial + (size_t)logits_row0 * c->H : nullptr;
+    if (segs) {   // the last row of every request, made contiguous in the K-split workspace
+      MI_CHECK((size_t)2 * nseg * c->H * 4 <= c->splitk_ws_bytes, "ragged batch: gather workspace too small");
+      Scope sc(c, MI_K_OTHER);
+      float* g0 = c->splitk_ws;
+      float* g1 = g0 + (size_t)nseg * c->H;
+      MI_TRY(launch_gather_rows(c->resid[cur], c->d_ctx, nseg, c->H, g0, s));
+      if (have_partial) MI_TRY(launch_gather_rows(c->partial, c->d_ctx, nseg, c->H, g1, s));
+      p.resid_in = g0;
+      p.partial = have_partial ? g1 : nullptr;
+    }
     p.resid_out = nullptr;
     p.gain = c->g_final; p.eps = k.rms_norm_eps;
     EpiArgs e{};
@@ -995,6 +1018,60 @@ int mi_forward_tokens(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_ids,
   MI_CHECK(tokens_out, "null argument");
   return forward_impl(c, B, S, input_ids, position_ids, seq_ids, block_table, MB, slot_mapping, SM, full_context_lens,
                       computed_context_lens, nullptr, sampling_params, seed, tokens_out);
+}
+
+int mi_forward_chunked(mi_ctx* c, int32_t n_req, int32_t total, const int64_t* input_ids, const int64_t* position_ids,
+                       const int64_t* slot_mapping, const int64_t* block_table, int32_t MB,
+                       const int64_t* full_context_lens, const int64_t* computed_context_lens, float* logits_out,
+                       const float* sampling_params, uint64_t seed, int64_t* tokens_out) {
+  if (c && c->owned_group)
+    return group_run(c->owned_group, [&](mi_ctx* rc, int) {
+      return mi_forward_chunked(rc, n_req, total, input_ids, position_ids, slot_mapping, block_table, MB, full_context_lens,
+                                computed_context_lens, logits_out, sampling_params, seed, tokens_out);
+    });
+  MI_CHECK(c && c->finalized, "mi_forward_chunked before mi_finalize");
+  MI_CHECK(input_ids && position_ids && slot_mapping && block_table && full_context_lens && computed_context_lens, "null argument");
+  MI_CHECK((logits_out != nullptr) != (tokens_out != nullptr), "exactly one of logits_out / tokens_out");
+  const mi_model_config& k = c->cfg;
+  MI_CHECK(n_req >= 1 && n_req <= k.max_num_seqs, "more requests than max_num_seqs");
+  MI_CHECK(total >= n_req && total <= c->max_rows, "token batch larger than the largest context-encoding bucket");
+  MI_CHECK(MB >= 1 && MB <= c->MB_cap, "bad block-table width");
+  MI_HIP(hipSetDevice(k.device_id));
+  hipStream_t s = c->stream;
+  const int bs = k.block_size, V = k.vocab_size;
+  set_input_views(c, false);
+  std::vector<Seg> segs((size_t)n_req);
+  int row = 0;
+  for (int i = 0; i < n_req; ++i) {
+    const int full = (int)full_context_lens[i], comp = (int)computed_context_lens[i];
+    const int n = full - comp;
+    MI_CHECK(comp >= 0 && n >= 1 && full <= k.max_model_len, "chunk bounds: need 0 <= computed < full <= max_model_len");
+    MI_CHECK(row + n <= total, "chunk lengths exceed the token batch");
+    MI_CHECK(ceil_div(full, bs) <= MB, "block_table narrower than the context");
+    for (int j = 0; j < MB; ++j) {
+      const int64_t blk = block_table[(size_t)i * MB + j];
+      if (j < ceil_div(full, bs)) MI_CHECK(blk >= 0 && blk < k.num_blocks, "block_table entry out of range inside the live context");
+      c->h_bt[(size_t)i * MB + j] = (int32_t)blk;
+    }
+    for (int t = 0; t < n; ++t) {
+      const int64_t id = input_ids[row + t], pos = position_ids[row + t], slot = slot_mapping[row + t];
+      MI_CHECK(id >= 0 && id < V, "token id out of range");
+      MI_CHECK(pos == comp + t, "positions of a chunk must continue its computed context");
+      MI_CHECK(slot >= -1 && slot < (int64_t)k.num_blocks * bs, "slot out of range");
+      c->h_ids[row + t] = (int32_t)id;
+      c->h_pos[row + t] = (int32_t)pos;
+      c->h_slots[row + t] = (int32_t)slot;
+    }
+    segs[i] = Seg{row, n, comp};
+    c->h_ctx[i] = row + n - 1;   // the request's last row: where its logits come from
+    row += n;
+  }
+  MI_CHECK(row == total, "chunk lengths do not add up to the token batch");
+  MI_HIP(hipMemcpyAsync(c->d_inputs, c->h_inputs, c->inputs_elems * 4, hipMemcpyHostToDevice, s));
+  MI_TRY(run_layers(c, total, false, 1, MB, 0, n_req, 0, segs.data(), n_req));
+  if (tokens_out) MI_TRY(sample_on_device(c, n_req, 0, sampling_params, seed, tokens_out));
+  else MI_TRY(fetch_logits(c, n_req, logits_out));
+  return prof_collect(c);
 }
 
 int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {

@@ -14,7 +14,7 @@ import gc
 import time
 from dataclasses import dataclass, field
 
-from ._vllm_compat import (HAVE_VLLM, KVCacheConfig, Request, SamplingParams, SimpleCacheConfig,
+from ._vllm_compat import (HAVE_VLLM, KVCacheConfig, Request, SamplingParams, Scheduler, SimpleCacheConfig,
                            SimpleDeviceConfig, SimpleModelConfig, SimpleParallelConfig,
                            SimpleSchedulerConfig, SimpleVllmConfig)
 from .core.scheduler import ContinuousBatchingMI355XScheduler
@@ -36,7 +36,8 @@ class RequestOutput:
 class MI355XEngine:
     def __init__(self, hf_config, model: str = "", *, max_model_len=2048, max_num_seqs=4, block_size=32,
                  num_gpu_blocks_override=None, enable_prefix_caching=True, tensor_parallel_size=1,
-                 dtype="bfloat16", override_mi355x_config: dict | None = None, seed=0, local_rank=0):
+                 dtype="bfloat16", override_mi355x_config: dict | None = None, seed=0, local_rank=0,
+                 enable_chunked_prefill=False, max_num_batched_tokens=None):
         if HAVE_VLLM:  # pragma: no cover
             raise RuntimeError("vLLM is installed: use vllm.LLM(...) — the plugin registers itself")
         cfg = SimpleVllmConfig(
@@ -45,10 +46,26 @@ class MI355XEngine:
             cache_config=SimpleCacheConfig(block_size=block_size, num_gpu_blocks_override=num_gpu_blocks_override,
                                            enable_prefix_caching=enable_prefix_caching),
             parallel_config=SimpleParallelConfig(tensor_parallel_size=tensor_parallel_size),
-            scheduler_config=SimpleSchedulerConfig(max_num_seqs=max_num_seqs, max_model_len=max_model_len),
+            scheduler_config=SimpleSchedulerConfig(max_num_seqs=max_num_seqs, max_model_len=max_model_len,
+                                                   chunked_prefill_enabled=bool(enable_chunked_prefill),
+                                                   max_num_batched_tokens=int(max_num_batched_tokens or 131072)),
             device_config=SimpleDeviceConfig("cpu"),
             additional_config={"override_mi355x_config": dict(override_mi355x_config or {})})
-        MI355XPlatform.check_and_update_config(cfg)
+        if enable_chunked_prefill:
+            # vLLM's native scheduler (the plugin's override is off: DISABLE_MI355X_CUSTOM_SCHEDULER=1,
+            # reference platform.py:131-175); `_vllm_compat.Scheduler` stands in for it here
+            import os
+            prev = os.environ.get("DISABLE_MI355X_CUSTOM_SCHEDULER")
+            os.environ["DISABLE_MI355X_CUSTOM_SCHEDULER"] = "1"
+            try:
+                MI355XPlatform.check_and_update_config(cfg)
+            finally:
+                if prev is None:
+                    del os.environ["DISABLE_MI355X_CUSTOM_SCHEDULER"]
+                else:
+                    os.environ["DISABLE_MI355X_CUSTOM_SCHEDULER"] = prev
+        else:
+            MI355XPlatform.check_and_update_config(cfg)
         self.vllm_config = cfg
         # ONE worker whatever tensor_parallel_size is (uni executor): the library context behind it
         # drives every GPU of the tensor-parallel group
@@ -68,7 +85,8 @@ class MI355XEngine:
             num_blocks = max(2, min(fit, need))
         self.worker.initialize_cache(num_blocks, 0)
         self.worker.initialize_from_config(KVCacheConfig(num_blocks=num_blocks))
-        self.scheduler = ContinuousBatchingMI355XScheduler(cfg, KVCacheConfig(num_blocks=num_blocks))
+        sched_cls = Scheduler if enable_chunked_prefill else ContinuousBatchingMI355XScheduler
+        self.scheduler = sched_cls(cfg, KVCacheConfig(num_blocks=num_blocks))
         self.outputs: dict[str, RequestOutput] = {}
         self._next_id = 0
         # What vLLM's engine core does once start-up is over: move everything allocated so far

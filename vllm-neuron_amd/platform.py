@@ -130,8 +130,8 @@ class MI355XPlatform(Platform):
             parallel_config.distributed_executor_backend = "uni"
 
         if native_scheduler:
-            logger.warning("vLLM's native V1 scheduler (chunked prefill) was requested; the MI355X "
-                           "runner implements the continuous-batching path only.")
+            logger.warning("The vLLM V1 native scheduler will be used with chunked prefill enabled: ragged "
+                           "token batches through mi_forward_chunked.")
             assert vllm_config.cache_config.block_size is not None, (
                 "When vLLM V1 native scheduler is enabled, block_size must be set.")
             return

@@ -116,6 +116,8 @@ class MI355XCausalLM(MI355XModelBase):
 
     def forward(self, input_ids, input_block_ids, **kwargs):
         cfg = self.mi355x_config
+        if cfg.get("chunked_prefill_config") is not None:
+            return self._forward_chunked(input_ids, **kwargs)
         with self._reordered(input_block_ids, input_ids=input_ids, **kwargs) as (seq_ids, inputs, restore):
             ids = inputs["input_ids"]
             if cfg.is_block_kv_layout:
@@ -144,6 +146,22 @@ class MI355XCausalLM(MI355XModelBase):
             logits = self.model.forward(ids, inputs["position_ids"], seq_ids, block_table, slot_mapping,
                                         inputs["full_context_lens"], computed, alias_ok=True)
             return restore(logits)
+
+    def _forward_chunked(self, input_ids, **inputs):
+        """One ragged token batch [1, sum S] (reference loader.py:339-361 with is_chunked_prefill):
+        logits (or sampled ids) of EVERY request's last scheduled token, in request order.  The
+        reference keeps only the rows whose prefill is complete (`prefill_completion_state`); here
+        all rows come back and the runner drops the incomplete ones after sampling, so the row
+        count always equals the number of scheduled requests."""
+        assert inputs.get("prefill_completion_state") is not None
+        cfg = self.mi355x_config
+        args = (input_ids, inputs["position_ids"], inputs["slot_mapping"], inputs["block_tables"],
+                inputs["full_context_lens"], inputs["computed_context_lens"])
+        if cfg.on_device_sampling_config:
+            self._sample_calls += 1
+            return self.model.forward_chunked(*args, sampling_params=inputs.get("sampling_params"),
+                                              seed=(self._sample_seed << 32) + self._sample_calls, tokens=True)
+        return self.model.forward_chunked(*args)
 
     def _batch_line_addressing(self, seq_ids, position_ids, full_context_lens, computed, S):
         """Contiguous ('batch line') KV expressed through the block pool: sequence id s owns
@@ -193,10 +211,18 @@ class MI355XCausalLM(MI355XModelBase):
         if tp_degree > 1 and len(tp_devices) != tp_degree:
             raise RuntimeError(f"tp_degree {tp_degree} needs {tp_degree} device ids, got {tp_devices}")
         from .._native import MI_TP_ALL_RANKS, MI_TP_TRANSPORT
+        buckets = list(cfg.get("context_encoding_buckets") or [])
+        max_num_seqs = int(cfg["batch_size"])
+        chunked = cfg.get("chunked_prefill_config")
+        if chunked:
+            # the reference compiles a batch-1 model over max_num_batched_tokens (loader.py:734-736);
+            # the ragged batch here holds up to chunked_prefill_config.max_num_seqs requests
+            max_num_seqs = int(getattr(chunked, "max_num_seqs", None) or cfg.get("scheduler_max_num_seqs") or max_num_seqs)
+            buckets = sorted(set(buckets + [int(cfg["max_context_length"])]))
         self.model = NativeModel(
             num_blocks=int(num_blocks), block_size=int(block_size),
-            max_num_seqs=int(cfg["batch_size"]), max_model_len=int(max_model_len),
-            ctx_buckets=cfg.get("context_encoding_buckets") or [],
+            max_num_seqs=max_num_seqs, max_model_len=int(max_model_len),
+            ctx_buckets=buckets,
             weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0,
             quant_type=_QUANT_TYPES[qtype] if quantized else 0,
             quantize_lm_head=int(quantized and not any("lm_head" in m for m in not_converted)),
@@ -311,8 +337,7 @@ def get_mi355x_model(model_config, cache_config, parallel_config, scheduler_conf
     if cfg.get("is_block_kv_layout"):
         cfg = _handle_pa_num_blocks(cache_config, cfg, override)
     cfg = _validate_mi355x_config(cache_config, scheduler_config, cfg)
-    if cfg.get("chunked_prefill_config"):
-        raise NotImplementedError("chunked prefill is not implemented on the MI355X plugin")
+    cfg["scheduler_max_num_seqs"] = scheduler_config.max_num_seqs
 
     model.load_weights(model_name_or_path=model_config.model, architecture=architecture, mi355x_config=cfg,
                        **native_kwargs)

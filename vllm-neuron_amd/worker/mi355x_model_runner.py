@@ -128,6 +128,7 @@ class MI355XModelRunner:
         self.is_block_kv_layout = cfg.is_block_kv_layout
         self.is_prefix_caching = cfg.is_prefix_caching
         self.is_chunked_prefill = cfg.chunked_prefill_config is not None
+        self.use_custom_seq_id_mapping = not self.is_chunked_prefill     # reference runner.py:133
         self.model.is_reorder_needed = not (self.is_prefix_caching or self.is_chunked_prefill)
         self._validate_sampling_configuration()
 
@@ -277,7 +278,7 @@ class MI355XModelRunner:
     # ---- input preparation --------------------------------------------------------------------
     def _prepare_model_input(self, scheduler_output) -> ModelInputForMI355X:
         if self.is_chunked_prefill:
-            raise NotImplementedError("chunked prefill inputs are not implemented on MI355X")
+            return self._finalize_chunked_prefill_inputs(self._prepare_chunked_prefill_inputs(scheduler_output))
         if self.is_prefix_caching and not scheduler_output.scheduled_new_reqs:
             return self._prepare_decode_inputs_incremental(scheduler_output)
         data, is_prefill = self._prepare_continuous_batching_inputs(scheduler_output)
@@ -332,6 +333,74 @@ class MI355XModelRunner:
             slot_mapping=torch.tensor(slots, dtype=torch.long).reshape(n, 1), block_tables=bt[:n],
             full_context_lens=pos_t + 1, computed_context_lens=pos_t, prefill_completion_state=None,
             sampling_params=self._sampling_params_if_used(input_tokens), multi_modal_kwargs=None, adapter_ids=None)
+
+    # ---- chunked prefill (vLLM's native scheduler; reference runner.py:654-680, 938-1051) ----------
+    def _prepare_chunked_prefill_inputs(self, scheduler_output) -> IntermediateInputData:
+        """A step is ONE ragged token batch: new requests are prompt chunks; cached requests are
+        either the next chunk of a prompt or the single next token of a request that generates."""
+        data = IntermediateInputData()
+        num_scheduled = scheduler_output.num_scheduled_tokens
+        for request_data in scheduler_output.scheduled_new_reqs:
+            if request_data.mm_features:
+                raise NotImplementedError("multimodal inputs are not supported on the MI355X plugin")
+            assert len(request_data.block_ids) == 1
+            self._append_chunk(data, request_data.req_id, request_data.prompt_token_ids, [],
+                               request_data.block_ids[0], request_data.num_computed_tokens,
+                               num_scheduled[request_data.req_id])
+        cached = scheduler_output.scheduled_cached_reqs
+        for i, req_id in enumerate(cached.req_ids):
+            state = self.requests[req_id]
+            self._append_chunk(data, req_id, state.prompt_token_ids, state.output_token_ids, state.block_ids[0],
+                               cached.num_computed_tokens[i], num_scheduled[req_id])
+        return data
+
+    def _append_chunk(self, data: IntermediateInputData, req_id, prompt, outputs, block_table, start, n) -> None:
+        end = start + n
+        data.request_ids.append(req_id)
+        # tokens start .. end-1 of the sequence (prompt, then what was generated so far)
+        if end <= len(prompt):
+            data.input_tokens.extend(prompt[start:end])
+        else:
+            seq = list(prompt) + list(outputs)
+            data.input_tokens.extend(seq[start:end])
+        data.position_ids.extend(range(start, end))
+        data.input_block_ids.append(0)
+        bs = self.cache_config.block_size
+        data.slot_mapping.extend(block_table[i // bs] * bs + i % bs for i in range(start, end))
+        data.block_tables.append(list(block_table))
+        data.full_context_lens.append(end)
+        data.computed_context_lens.append(start)
+        data.prefill_completion_state.append(end >= len(prompt))
+
+    def _finalize_chunked_prefill_inputs(self, data: IntermediateInputData) -> ModelInputForMI355X:
+        input_tokens = torch.tensor(data.input_tokens, dtype=torch.long).reshape(1, -1)
+        max_blocks = max(len(b) for b in data.block_tables)
+        block_tables = torch.tensor([b + [self._BLOCK_TABLE_PAD] * (max_blocks - len(b)) for b in data.block_tables],
+                                    dtype=torch.long)
+        return ModelInputForMI355X(
+            request_ids=data.request_ids, input_tokens=input_tokens,
+            position_ids=torch.tensor(data.position_ids, dtype=torch.long).reshape(1, -1),
+            input_block_ids=torch.tensor(data.input_block_ids[:1], dtype=torch.long),
+            slot_mapping=torch.tensor(data.slot_mapping, dtype=torch.long), block_tables=block_tables,
+            full_context_lens=torch.tensor(data.full_context_lens, dtype=torch.long),
+            computed_context_lens=torch.tensor(data.computed_context_lens, dtype=torch.long),
+            prefill_completion_state=torch.tensor(data.prefill_completion_state, dtype=torch.bool),
+            sampling_params=self._chunked_sampling_params(data), multi_modal_kwargs=None, adapter_ids=None)
+
+    def _chunked_sampling_params(self, data: IntermediateInputData):
+        """(top_k, top_p, temperature) rows in the order of the ragged batch's requests."""
+        if self.model.mi355x_config.on_device_sampling_config is None:
+            return None
+        max_topk = min(self.model_config.get_vocab_size(), self._MAX_DEVICE_SAMPLING_TOP_K)
+        rows = []
+        for rid in data.request_ids:
+            sp = self.requests[rid].sampling_params
+            top_k = sp.top_k if 0 < (sp.top_k or 0) < max_topk else max_topk
+            temperature = sp.temperature
+            if temperature == 0.0:
+                top_k, temperature = 1, 1.0
+            rows.append([float(top_k), float(sp.top_p), float(temperature)])
+        return torch.tensor(rows, dtype=torch.float32)
 
     def _prepare_continuous_batching_inputs(self, scheduler_output) -> Tuple[IntermediateInputData, bool]:
         """New requests are prefills, cached requests are decodes; the scheduler never mixes
@@ -456,8 +525,19 @@ class MI355XModelRunner:
             hidden_states = hidden_states[reorder]     # (a [B, V] copy: only when the orders differ)
         try:
             if self.model.mi355x_config.on_device_sampling_config is None:
-                return self._cpu_sample(hidden_states, model_input)
-            return self.model.sample(logits=hidden_states)
+                out = self._cpu_sample(hidden_states, model_input)
+            else:
+                out = self.model.sample(logits=hidden_states)
+            if model_input.prefill_completion_state is not None:
+                # chunked prefill: a request whose prompt is not fully encoded yet produces no token
+                # (reference runner.py:1060-1063 marks those rows -1; -1 rows are stripped downstream)
+                done = {rid: bool(f) for rid, f in zip(model_input.request_ids, model_input.prefill_completion_state.tolist())}
+                ids = out.sampled_token_ids.clone()
+                for row, rid in enumerate(self.input_batch.req_ids):
+                    if not done[rid]:
+                        ids[row] = -1
+                out = SamplerOutput(sampled_token_ids=ids, logprobs_tensors=out.logprobs_tensors)
+            return out
         except Exception as e:
             logger.error("Sampling failed for requests %s: %s", model_input.request_ids, e)
             raise RuntimeError(f"Sampling operation failed: {str(e)}") from e
