@@ -324,7 +324,8 @@ class FakeModel:
 
     def __call__(self, **kw):
         self.calls.append(kw)
-        B = kw["input_ids"].shape[0]
+        pcs = kw.get("prefill_completion_state")
+        B = len(pcs) if pcs is not None else kw["input_ids"].shape[0]     # chunked prefill: one row per request
         logits = torch.zeros(B, self.vocab)
         logits[torch.arange(B), 10 + torch.arange(B)] = 5.0
         return logits
@@ -429,6 +430,66 @@ def test_incremental_decode_inputs_equal_the_rebuilt_ones():
     step(["a", "c"], [None, None], [33, 72], finished=["b"])             # c moves up a row
     r.execute_model(sched_out([new_req("d", list(range(10)), [12])]))    # a prefill in between
     step(["a", "c", "d"], [None, None, None], [34, 73, 10])              # d takes a fresh row
+
+
+def _chunked_runner():
+    r = make_runner()
+    r.is_chunked_prefill = True
+    r.use_custom_seq_id_mapping = False
+    r.cache_config.block_size = 8
+    r.model.mi355x_config.chunked_prefill_config = SimpleNamespace(max_num_seqs=4)
+    return r
+
+
+def test_chunked_prefill_new_request_chunk():                   # reference test_model_runner.py:1469-1510
+    r = _chunked_runner()
+    so = SchedulerOutput(scheduled_new_reqs=[new_req("req1", [1, 2, 3, 4, 5], [0, 1, 2])],
+                         scheduled_cached_reqs=CachedRequestData(), num_scheduled_tokens={"req1": 3},
+                         total_num_scheduled_tokens=3, finished_req_ids=set())
+    data = r._prepare_chunked_prefill_inputs(so)
+    assert data.request_ids == ["req1"] and data.input_tokens == [1, 2, 3]      # the first 3 tokens
+    assert data.position_ids == [0, 1, 2] and data.slot_mapping == [0, 1, 2]
+    assert data.full_context_lens == [3] and data.computed_context_lens == [0]
+    assert data.prefill_completion_state == [False]                             # more chunks remain
+
+
+def test_chunked_prefill_cached_requests_and_finalize():        # reference runner.py:964-1051
+    """A ragged step: the next chunk of a long prompt + a request that generates.  (The reference's
+    KAT at test_model_runner.py:1252-1290 feeds a state no scheduler produces -- output tokens on a
+    prompt that is not encoded yet -- and expects 3 tokens for 2 scheduled; here a chunk always has
+    exactly num_scheduled_tokens tokens, taken from prompt + outputs at positions start .. end-1.)"""
+    r = _chunked_runner()
+    r.requests = {
+        "long": SimpleNamespace(prompt_token_ids=list(range(100, 120)), output_token_ids=[], block_ids=([3, 4, 5],),
+                                sampling_params=SamplingParams(temperature=0.0)),
+        "gen": SimpleNamespace(prompt_token_ids=[1, 2, 3, 4, 5, 6, 7], output_token_ids=[8, 9], block_ids=([0, 1],),
+                               sampling_params=SamplingParams(temperature=0.0)),
+    }
+    cached = CachedRequestData(req_ids=["long", "gen"], resumed_from_preemption=[False, False], new_token_ids=[[], []],
+                               new_block_ids=[None, None], num_computed_tokens=[8, 8])
+    so = SchedulerOutput(scheduled_new_reqs=[], scheduled_cached_reqs=cached, num_scheduled_tokens={"long": 12, "gen": 1},
+                         total_num_scheduled_tokens=13, finished_req_ids=set())
+    data = r._prepare_chunked_prefill_inputs(so)
+    assert data.input_tokens == list(range(108, 120)) + [9]                      # the last output token is fed back
+    assert data.position_ids == list(range(8, 20)) + [8]
+    assert data.slot_mapping == [4 * 8 + i for i in range(8)] + [5 * 8 + i for i in range(4)] + [1 * 8 + 0]
+    assert data.full_context_lens == [20, 9] and data.computed_context_lens == [8, 8]
+    assert data.prefill_completion_state == [True, True]
+    m = r._finalize_chunked_prefill_inputs(data)
+    assert m.input_tokens.shape == (1, 13) and m.position_ids.shape == (1, 13) and m.slot_mapping.shape == (13,)
+    assert m.block_tables.tolist() == [[3, 4, 5], [0, 1, 0]]                     # padded with block 0
+    assert m.prefill_completion_state.dtype == torch.bool and m.input_block_ids.tolist() == [0]
+    assert m.full_context_lens.tolist() == [20, 9] and m.sampling_params is None  # CPU sampling: rows not built
+
+
+def test_chunked_prefill_incomplete_rows_yield_no_token():      # reference runner.py:1060-1063
+    r = _chunked_runner()
+    r.execute_model(SchedulerOutput(
+        scheduled_new_reqs=[new_req("p", list(range(30)), [0, 1, 2, 3]), new_req("q", [5, 6, 7], [4])],
+        scheduled_cached_reqs=CachedRequestData(), num_scheduled_tokens={"p": 16, "q": 3},
+        total_num_scheduled_tokens=19, finished_req_ids=set()))
+    assert r.model.calls[-1]["prefill_completion_state"].tolist() == [False, True]
+    assert r.requests["p"].output_token_ids == [] and len(r.requests["q"].output_token_ids) == 1
 
 
 def test_finished_requests_free_seq_ids():                      # tests :683-718, :1020-1049
