@@ -107,6 +107,17 @@ int mi_load_weight(mi_ctx* ctx, const char* name, const void* host, int32_t dtyp
 /* Bench/smoke only: N(0, std) matrices from a counter-based RNG in LOGICAL coordinates
  * (identical values whatever the sharding); norm gains 1. */
 int mi_init_synthetic_weights(mi_ctx* ctx, uint64_t seed, float std);
+/* Weight artifacts -- the counterpart of the reference's compiled-artifact directory
+ * (loader.py:160-226, keyed by a config hash there; the Python mirror keys the directory the same
+ * way).  mi_save_weights writes this context's device images (quantized, tiled, sharded: what
+ * mi_load_weight made) to <dir>/rank<r>_of<T>.miw; mi_load_weights_file streams such a file back
+ * into HBM in place of every mi_load_weight call, and returns MI_EINVAL when the file is missing
+ * or was made for another model, quantization, sharding or tile format (the caller then loads the
+ * checkpoint the long way and saves again).  Also the home of quantized_checkpoints_path
+ * (loader.py:888-891). */
+int mi_save_weights(mi_ctx* ctx, const char* dir);
+int mi_load_weights_file(mi_ctx* ctx, const char* dir);
+
 /* Re-size the KV pool before mi_finalize: vLLM decides the block count after the weights
  * are resident (worker.determine_available_memory -> KVCacheConfig.num_blocks; the reference's
  * NxDI takes it at compile time as pa_num_blocks, loader.py:775-776). */

@@ -30,7 +30,8 @@ MB = MAXLEN // BS
 NB = 1 + NSEQ * MB
 
 
-def native_model(cfg, weights, weight_dtype="bf16", quant_type="per_tensor_symmetric", use_graphs=1, a8=0):
+def native_model(cfg, weights, weight_dtype="bf16", quant_type="per_tensor_symmetric", use_graphs=1, a8=0,
+                 artifacts=None):
     from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
     rs = cfg.rope_scaling or {}
     m = NativeModel(
@@ -44,7 +45,14 @@ def native_model(cfg, weights, weight_dtype="bf16", quant_type="per_tensor_symme
         num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
         weight_dtype=MI_W[weight_dtype], quant_type=MI_Q[quant_type], quantize_lm_head=1,
         tp_degree=1, tp_rank=0, device_id=0, use_graphs=use_graphs, prefill_fp8_activations=a8)
-    m.load_state_dict(weights)
+    if artifacts is not None:
+        try:
+            m.load_artifacts(artifacts)           # weight images saved by NativeModel.save_artifacts
+        except Exception:
+            m.close()
+            raise
+    else:
+        m.load_state_dict(weights)
     m.finalize()
     return m
 

@@ -80,6 +80,36 @@ def test_sampled_ids_follow_the_stated_rule(V):
     assert _op_sample(logits, params, 99) == _op_sample(logits, params, 99)
 
 
+@pytest.mark.parametrize("V", [4099, 128256])
+def test_mass_ties_at_the_threshold_never_evict_larger_logits(V):
+    """More exact ties at the top-k threshold than the candidate buffer holds (1024): the sampler
+    must keep every strictly larger logit and, of the ties, the lowest vocabulary indices --
+    whatever the order the threads meet them in (the arrival-order collection could
+    drop larger logits).  With top_p = 1 every kept candidate can be drawn: over many seeds the
+    drawn ids must stay inside the oracle's kept set and cover the large logits."""
+    g = torch.Generator().manual_seed(V)
+    logits = torch.full((2, V), -4.0)
+    tie_idx = torch.randperm(V, generator=g)[:3000]                  # 3000 exact ties at 1.0
+    logits[:, tie_idx] = 1.0
+    rest = torch.tensor(sorted(set(range(V)) - set(tie_idx.tolist())))
+    big = rest[torch.randperm(len(rest), generator=g)[:10]]
+    logits[0, big] = torch.linspace(2.0, 3.0, len(big))               # strictly above the ties
+    tk = 50
+    keep, _ = osamp.kept_distribution(logits[0].numpy(), tk, 1.0, 1.0)
+    keep = set(keep.tolist())
+    lowest_ties = sorted(tie_idx.tolist())[:tk - len(big)]
+    assert keep == set(big.tolist()) | set(lowest_ties)
+    params = torch.tensor([[float(tk), 1.0, 1.0]] * 2)
+    seen = set()
+    for seed in range(300):
+        got = _op_sample(logits, params, seed)
+        assert got[0] in keep, (seed, got[0])
+        assert _agrees(logits[0].numpy(), tk, 1.0, 1.0, seed, 0, got[0])
+        assert got == _op_sample(logits, params, seed)               # deterministic
+        seen.add(got[0])
+    assert seen & set(big.tolist())                                   # the large logits are drawn (they carry ~45 % of the mass)
+
+
 def test_empirical_distribution_matches_the_nucleus():
     V, tk, tp, tt = 512, 8, 0.9, 1.3
     logits = torch.randn(1, V, generator=torch.Generator().manual_seed(3)) * 2

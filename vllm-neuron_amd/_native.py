@@ -65,6 +65,8 @@ _SIGS = {
     "mi_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32,
                                  C.POINTER(C.c_int64), C.c_int32]),
     "mi_init_synthetic_weights": (C.c_int, [C.c_void_p, C.c_uint64, C.c_float]),
+    "mi_save_weights": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mi_load_weights_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mi_set_num_blocks": (C.c_int, [C.c_void_p, C.c_int32]),
     "mi_finalize": (C.c_int, [C.c_void_p]),
     "mi_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -195,6 +197,16 @@ class NativeModel:
         for name, t in weights.items():
             if t.dim() in (1, 2):
                 self.load_weight(name, t)
+
+    def save_artifacts(self, directory: str) -> None:
+        """Write this context's device weight images (one file per rank) under `directory`."""
+        os.makedirs(directory, exist_ok=True)
+        check(self.lib.mi_save_weights(self._ctx, os.fsencode(directory)))
+
+    def load_artifacts(self, directory: str) -> None:
+        """Load the device weight images saved by `save_artifacts`; ValueError when they are
+        missing or were made for another configuration."""
+        check(self.lib.mi_load_weights_file(self._ctx, os.fsencode(directory)))
 
     def init_synthetic_weights(self, seed: int = 1, std: float = 0.02) -> None:
         check(self.lib.mi_init_synthetic_weights(self._ctx, seed, std))

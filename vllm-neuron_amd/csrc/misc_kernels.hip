@@ -279,18 +279,47 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     __syncthreads();
   }
   const uint32_t kth = s_prefix;          // key of the top_k-th largest element
-  // ---- candidates: everything >= that key (ties at the threshold included, capped) ---------
-  if (tid == 0) s_count = 0;
+  // ---- candidates: exactly top_k of them ---------------------------------------------------
+  // 1. every logit strictly above the threshold key (fewer than top_k by construction: any order,
+  //    the sort below fixes it);  2. of the logits AT the threshold -- there may be many exact ties --
+  //    the `s_remaining` with the LOWEST vocabulary indices, found by walking the vocabulary in index
+  //    order.  (Collecting ">= threshold" in arrival order, as a first version did, could fill the
+  //    candidate buffer with ties and drop larger logits, and depended on thread timing.)
+  __shared__ unsigned int wave_cnt[kSampleThreads / 64];
+  __shared__ unsigned int s_ties;
+  if (tid == 0) { s_count = 0; s_ties = 0; }
   for (int i = tid; i < kSampleCand; i += kSampleThreads) { cand_v[i] = -INFINITY; cand_i[i] = 0x7fffffff; }
   __syncthreads();
   for (int v = tid; v < V; v += kSampleThreads) {
     const float x = at(v);
-    if (f32_order_key(x) >= kth) {
+    if (f32_order_key(x) > kth) {
       const unsigned int slot = atomicAdd(&s_count, 1u);
       if (slot < (unsigned)kSampleCand) { cand_v[slot] = x; cand_i[slot] = v; }
     }
   }
   __syncthreads();
+  const unsigned int n_gt = min(s_count, (unsigned)top_k);
+  const unsigned int need = (unsigned)top_k - n_gt;        // ties to take (>= 1: the threshold element itself)
+  for (int base = 0; base < V; base += kSampleThreads) {
+    if (s_ties >= need) break;                              // uniform: written behind the barrier below
+    const int v = base + tid;
+    const float x = v < V ? at(v) : 0.f;
+    const bool tie = v < V && f32_order_key(x) == kth;
+    const unsigned long long bal = __ballot(tie);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wave_cnt[wv] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned int before = 0, total = 0;
+    for (int w = 0; w < kSampleThreads / 64; ++w) {
+      if (w < wv) before += wave_cnt[w];
+      total += wave_cnt[w];
+    }
+    const unsigned int t = s_ties + before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (tie && t < need) { cand_v[n_gt + t] = x; cand_i[n_gt + t] = v; }
+    __syncthreads();
+    if (tid == 0) s_ties += total;
+    __syncthreads();
+  }
   // bitonic sort of the kSampleCand slots: value descending, index ascending (deterministic)
   for (int size = 2; size <= kSampleCand; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {

@@ -693,6 +693,130 @@ int mi_init_synthetic_weights(mi_ctx* c, uint64_t seed, float std) {
   return MI_OK;
 }
 
+// ---- weight artifacts: the device images (quantized, tiled, sharded) of one rank, on disk --------
+// The counterpart of the reference's compiled-artifact directory (loader.py:160-226): a restart
+// skips reading the bf16 checkpoint, quantizing and re-tiling, and streams the ready-made images
+// straight into HBM.  One file per rank: header (format + everything the images depend on), then
+// every tensor in a fixed order as [uint64 nbytes][bytes].
+namespace {
+struct ArtifactHeader {
+  char magic[8];            // "MI355XW\0"
+  int32_t version;          // of this file layout
+  int32_t tile_format;      // of the weight tiling (mi_common.h): bump when the kernels' layout changes
+  int32_t geo[9];           // layers, hidden, heads, kv heads, head dim, intermediate, vocab, qkv_bias, tie
+  int32_t weight_dtype, quant_type, quantize_lm_head, tp_degree, tp_rank;
+};
+constexpr int32_t kArtifactVersion = 1, kTileFormat = 1;
+
+void make_header(const mi_ctx* c, ArtifactHeader& h) {
+  const mi_model_config& k = c->cfg;
+  h = ArtifactHeader{};
+  memcpy(h.magic, "MI355XW", 8);
+  h.version = kArtifactVersion;
+  h.tile_format = kTileFormat;
+  const int32_t g[9] = {k.num_layers, k.hidden_size, k.num_heads, k.num_kv_heads, k.head_dim, k.intermediate_size,
+                        k.vocab_size, k.qkv_bias, k.tie_word_embeddings};
+  memcpy(h.geo, g, sizeof g);
+  h.weight_dtype = k.weight_dtype; h.quant_type = k.quant_type; h.quantize_lm_head = k.quantize_lm_head;
+  h.tp_degree = k.tp_degree; h.tp_rank = k.tp_rank;
+}
+
+// every device tensor of a rank, in file order
+void artifact_tensors(mi_ctx* c, std::vector<std::pair<void*, size_t>>& out) {
+  auto lin = [&](Linear& L) {
+    out.push_back({L.w, L.bytes()});
+    out.push_back({L.scale, (size_t)L.N * 4});
+    if (L.bias) out.push_back({L.bias, (size_t)L.N * 4});
+  };
+  for (auto& W : c->layers) {
+    lin(W.qkv); lin(W.o); lin(W.gu); lin(W.down);
+    out.push_back({W.g_in, (size_t)c->H * 4});
+    out.push_back({W.g_post, (size_t)c->H * 4});
+  }
+  lin(c->lm_head);
+  out.push_back({c->g_final, (size_t)c->H * 4});
+  out.push_back({c->embed, (size_t)c->cfg.vocab_size * c->H * 2});
+}
+
+void artifact_file(const mi_ctx* c, const char* dir, std::string& out) {
+  out = std::string(dir) + "/rank" + std::to_string(c->cfg.tp_rank) + "_of" + std::to_string(c->cfg.tp_degree) + ".miw";
+}
+constexpr size_t kArtifactChunk = (size_t)64 << 20;
+}  // namespace
+
+int mi_save_weights(mi_ctx* c, const char* dir) {
+  MI_CHECK(c && dir, "null argument");
+  if (c->owned_group) return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_save_weights(rc, dir); });
+  MI_CHECK(c->have_lm_head, "mi_save_weights: the weights are not loaded yet");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  std::string path;
+  artifact_file(c, dir, path);
+  const std::string tmp = path + ".part";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) { set_error("mi_save_weights: cannot create " + tmp); return MI_EINVAL; }
+  void* stage = nullptr;
+  if (hipHostMalloc(&stage, kArtifactChunk, hipHostMallocDefault) != hipSuccess) { fclose(f); set_error("mi_save_weights: pinned staging"); return MI_ENOMEM; }
+  ArtifactHeader h;
+  make_header(c, h);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  std::vector<std::pair<void*, size_t>> ts;
+  artifact_tensors(c, ts);
+  MI_HIP(hipStreamSynchronize(c->stream));
+  for (auto& t : ts) {
+    const uint64_t n = t.second;
+    ok = ok && fwrite(&n, 8, 1, f) == 1;
+    for (size_t off = 0; ok && off < t.second; off += kArtifactChunk) {
+      const size_t m = std::min(kArtifactChunk, t.second - off);
+      if (hipMemcpy(stage, (char*)t.first + off, m, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+      else ok = fwrite(stage, 1, m, f) == m;
+    }
+  }
+  hipHostFree(stage);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { remove(tmp.c_str()); set_error("mi_save_weights: write to " + tmp + " failed"); return MI_EINVAL; }
+  if (rename(tmp.c_str(), path.c_str()) != 0) { set_error("mi_save_weights: cannot rename to " + path); return MI_EINVAL; }
+  return MI_OK;
+}
+
+// MI_EINVAL (-> ValueError in the Python mirror, like a config mismatch in the reference) when the
+// file is missing or was made for another model / quantization / sharding / tile format.
+int mi_load_weights_file(mi_ctx* c, const char* dir) {
+  MI_CHECK(c && dir, "null argument");
+  if (c->owned_group) return group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_load_weights_file(rc, dir); });
+  MI_CHECK(!c->finalized, "mi_load_weights_file after mi_finalize");
+  MI_HIP(hipSetDevice(c->cfg.device_id));
+  std::string path;
+  artifact_file(c, dir, path);
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_error("weight artifacts not found: " + path); return MI_EINVAL; }
+  ArtifactHeader h{}, want;
+  make_header(c, want);
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(&h, &want, sizeof h) != 0) {
+    fclose(f);
+    set_error("weight artifacts at " + path + " were made for another model / quantization / sharding / format");
+    return MI_EINVAL;
+  }
+  void* stage = nullptr;
+  if (hipHostMalloc(&stage, kArtifactChunk, hipHostMallocDefault) != hipSuccess) { fclose(f); set_error("pinned staging"); return MI_ENOMEM; }
+  std::vector<std::pair<void*, size_t>> ts;
+  artifact_tensors(c, ts);
+  bool ok = true;
+  for (auto& t : ts) {
+    uint64_t n = 0;
+    ok = ok && fread(&n, 8, 1, f) == 1 && n == t.second;
+    for (size_t off = 0; ok && off < t.second; off += kArtifactChunk) {
+      const size_t m = std::min(kArtifactChunk, t.second - off);
+      ok = fread(stage, 1, m, f) == m && hipMemcpy((char*)t.first + off, stage, m, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) break;
+  }
+  hipHostFree(stage);
+  fclose(f);
+  if (!ok) { set_error("weight artifacts at " + path + " are truncated or do not match this context's tensors"); return MI_EINVAL; }
+  c->have_lm_head = true;
+  return MI_OK;
+}
+
 int mi_set_num_blocks(mi_ctx* c, int32_t num_blocks) {
   MI_CHECK(c, "null argument");
   if (c->owned_group) {

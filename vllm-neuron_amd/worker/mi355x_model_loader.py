@@ -198,9 +198,6 @@ class MI355XCausalLM(MI355XModelBase):
             num_blocks = cfg["batch_size"] + 1
         self.native_block_size = block_size
         quantized = bool(cfg.get("quantized"))
-        if quantized and cfg.get("quantized_checkpoints_path"):
-            raise NotImplementedError("pre-quantized checkpoints are not supported yet: weights are "
-                                      "quantized at load (quantized_checkpoints_path must be unset)")
         qdtype = cfg.get("quantization_dtype", "int8")
         qtype = cfg.get("quantization_type", "per_tensor_symmetric")
         if quantized and (qdtype not in _QUANT_DTYPES or qtype not in _QUANT_TYPES):
@@ -237,13 +234,57 @@ class MI355XCausalLM(MI355XModelBase):
             **geo)
         synthetic = cfg.get("synthetic_weights")
         state_dict = cfg.get("state_dict")
+        # Device-ready weight images on disk (quantized, tiled, sharded), the counterpart of the
+        # reference's compiled-artifact directory (loader.py:160-226): try them first; on a miss take
+        # the checkpoint the long way (read, quantize, tile) and leave the images for the next start.
+        artifacts = self._artifact_dir(model_name_or_path, cfg, geo, quantized, qdtype, qtype, tp_degree)
+        if artifacts is not None:
+            try:
+                self.model.load_artifacts(artifacts)
+                logger.info("Successfully loaded pre-built weight artifacts from %s", artifacts)
+                self.compiled_artifacts_path, self.loaded_from_artifacts = artifacts, True
+                return True, artifacts
+            except (FileNotFoundError, ValueError) as e:
+                logger.warning("Exception: %s", e)
+                logger.warning("Unable to find pre-built weight artifacts under %s. Rebuilding...", artifacts)
         if synthetic is not None:
             self.model.init_synthetic_weights(int(synthetic.get("seed", 1)), float(synthetic.get("std", 0.02)))
         elif state_dict is not None:
             self.model.load_state_dict(state_dict)
         else:
             self._load_safetensors_dir(model_name_or_path)
-        return True, None
+        self.compiled_artifacts_path, self.loaded_from_artifacts = artifacts, False
+        if artifacts is not None:
+            self.model.save_artifacts(artifacts)
+            logger.info("Saved weight artifacts to %s", artifacts)
+        return False, artifacts
+
+    @staticmethod
+    def _artifact_dir(model_name_or_path, cfg, geo, quantized, qdtype, qtype, tp_degree):
+        """Where this configuration's weight images live, or None for no caching.
+          * quantized_checkpoints_path (loader.py:888-891): the directory the quantized weights are
+            kept in -- used as given;
+          * MI355X_COMPILED_ARTIFACTS (the reference's NEURON_COMPILED_ARTIFACTS, loader.py:198-199): as given;
+          * a local checkpoint directory: <model>/mi355x-compiled-artifacts/<md5 of the configuration>
+            (loader.py:186-210);
+          * synthetic or in-memory weights without one of the two explicit paths: not cached."""
+        import hashlib
+        import json
+        explicit = (cfg.get("quantized_checkpoints_path") if quantized else None) or os.getenv("MI355X_COMPILED_ARTIFACTS")
+        if explicit:
+            return str(explicit)
+        if cfg.get("synthetic_weights") is not None or cfg.get("state_dict") is not None:
+            return None
+        if not (model_name_or_path and os.path.isdir(model_name_or_path)):
+            return None
+        files = sorted(glob.glob(os.path.join(model_name_or_path, "*.safetensors")))
+        ident = [(os.path.basename(f), os.path.getsize(f), int(os.path.getmtime(f))) for f in files]
+        key = json.dumps({"geo": geo, "quantized": quantized, "dtype": qdtype if quantized else "bf16",
+                          "type": qtype if quantized else None, "tp": tp_degree,
+                          "lm_head": not any("lm_head" in m for m in (cfg.get("modules_to_not_convert") or [])),
+                          "checkpoint": ident}, sort_keys=True)
+        hashed = hashlib.md5(key.encode("utf-8")).hexdigest()
+        return os.path.join(model_name_or_path, "mi355x-compiled-artifacts", hashed)
 
     def _load_safetensors_dir(self, path: str) -> None:
         from safetensors import safe_open
