@@ -180,13 +180,18 @@ int mi_replay_decode(mi_ctx* ctx, int32_t steps, float* elapsed_ms);
 int mi_replay_decode_classes(mi_ctx* ctx, int32_t steps, uint32_t class_mask, float* elapsed_ms);
 
 typedef struct mi_kv_stats_t {
-  int64_t kv_bytes, weight_bytes, workspace_bytes, device_free_bytes, device_total_bytes;
+  int64_t kv_bytes, weight_bytes;
+  int64_t workspace_bytes;   /* before mi_finalize: what it will allocate besides the KV pool; after: what it did */
+  int64_t device_free_bytes, device_total_bytes;
   int32_t num_blocks, block_size, num_kv_heads_local, head_dim, num_layers;
   /* token-generation block tables are device-resident: rows re-sent because the caller's row
    * changed (new request, block appended) vs rows found unchanged since the previous step */
   int64_t block_table_rows_sent, block_table_rows_kept;
 } mi_kv_stats_t;
 int mi_kv_stats(mi_ctx* ctx, mi_kv_stats_t* out);
+/* Bytes ONE block costs on a GPU across all layers (K and V, this rank's kv heads): vLLM sizes the
+ * cache from a single-layer spec (runner.get_kv_cache_spec), the pool holds num_layers of them. */
+int64_t mi_kv_bytes_per_block(mi_ctx* ctx);
 
 /* The pinned host buffer [max_num_seqs][vocab_size] fp32 the logits land in.  Passing it as
  * mi_forward's logits_out skips the final host copy: the caller reads the logits in place, valid

@@ -350,3 +350,27 @@ def test_on_device_sampling_config_is_accepted_and_routes_to_tokens():
     assert torch.equal(p1, params) and s1 == (7 << 32) + 1 and s2 == (7 << 32) + 2
     so = m.sample(logits=out)
     assert so.sampled_token_ids.shape == (B, 1)
+
+
+def test_installed_layout_imports_without_the_checkout(tmp_path):
+    """`setup.py` must ship the real package (package_dir onto `vllm-neuron_amd/`) and
+    the HIP library, not the in-tree import stub.  Build the package files into a scratch directory
+    (no hipcc run: the in-tree library is reused) and import from there with the repository out of
+    sys.path: the entry point resolves and `_native` finds its library inside the installed package."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MI355X_SKIP_HIP_BUILD="1")
+    build_lib = tmp_path / "lib"
+    r = subprocess.run([sys.executable, "setup.py", "-q", "build_py", "--build-lib", str(build_lib)], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    pkg = build_lib / "vllm_neuron_amd"
+    assert (pkg / "csrc" / "libmi355x_vllm.so").exists() and (pkg / "worker" / "mi355x_worker.py").exists()
+    code = ("import sys; sys.path = [p for p in sys.path if p not in ('', %r)]; sys.path.insert(0, %r);"
+            "import vllm_neuron_amd, vllm_neuron_amd._native as n, vllm_neuron_amd.platform as p;"
+            "assert vllm_neuron_amd.__file__.startswith(%r), vllm_neuron_amd.__file__;"
+            "assert n.LIB_PATH.startswith(%r) and n.load_library().mi_version() >= 3;"
+            "print(vllm_neuron_amd.PLATFORM_QUALNAME)") % (ROOT, str(build_lib), str(build_lib), str(build_lib))
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k != "PYTHONPATH"})
+    assert r.returncode == 0 and "MI355XPlatform" in r.stdout, r.stderr[-2000:]

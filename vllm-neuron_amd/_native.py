@@ -80,6 +80,7 @@ _SIGS = {
     "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "mi_replay_decode_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
+    "mi_kv_bytes_per_block": (C.c_int64, [C.c_void_p]),
     "mi_stream": (C.c_void_p, [C.c_void_p]),
     "mi_logits_buffer": (C.c_void_p, [C.c_void_p]),
     "mi_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -343,6 +344,9 @@ class NativeModel:
         s = MiKvStats()
         check(self.lib.mi_kv_stats(self._ctx, C.byref(s)))
         return {f: getattr(s, f) for f, _ in MiKvStats._fields_}
+
+    def kv_bytes_per_block(self) -> int:
+        return int(self.lib.mi_kv_bytes_per_block(self._ctx))
 
     def stream_handle(self) -> int:
         return int(self.lib.mi_stream(self._ctx) or 0)

@@ -829,6 +829,27 @@ int mi_set_num_blocks(mi_ctx* c, int32_t num_blocks) {
   return MI_OK;
 }
 
+// bytes mi_finalize allocates besides the KV pool (activations, exchange buffers, scratch): what
+// has to be kept out of the memory offered to vLLM for KV blocks
+static size_t workspace_estimate(const mi_ctx* c) {
+  const mi_model_config& k = c->cfg;
+  const size_t R = (size_t)c->max_rows, H = (size_t)c->H;
+  size_t b = 3 * R * H * 4 + R * std::max<size_t>(H, c->I_l) * 2 + 2 * R * c->q_dim * 2 + R * c->I_l * 2;
+  if (k.prefill_fp8_activations) b += R * std::max<size_t>(std::max<size_t>(H, c->I_l), c->q_dim) + R * 4;
+  b += (size_t)64 << 20;                                                   // split-K workspace
+  b += (size_t)k.max_num_seqs * c->V_l * 4 * (1 + (k.tp_degree > 1 ? k.tp_degree : 0));
+  b += attn_scratch_bytes(k.max_num_seqs, c->nh_l, c->hd);
+  b += (size_t)k.max_model_len * c->hd * 4;                                 // rotary tables
+  if (k.tp_degree > 1) b += 8 * R * H + 4 * (R * H / k.tp_degree + 1024);   // exchange slots (tp_group.hip)
+  return b + ((size_t)8 << 20);                                             // inputs, small buffers
+}
+
+int64_t mi_kv_bytes_per_block(mi_ctx* c) {
+  if (!c) return 0;
+  if (c->owned_group) c = c->owned_group->ranks[0];
+  return (int64_t)c->cfg.num_layers * 2 * c->nkv_l * c->cfg.block_size * c->hd * 2;
+}
+
 int mi_finalize(mi_ctx* c) {
   MI_CHECK(c, "null argument");
   if (c->owned_group) {
@@ -849,6 +870,18 @@ int mi_finalize(mi_ctx* c) {
   // KV pool, zero-filled: stale or never-written rows must hold finite values
   c->kv_half = (size_t)k.num_blocks * c->nkv_l * k.block_size * c->hd;
   const size_t kv_elems = c->kv_half * 2 * k.num_layers;
+  {
+    size_t fr = 0, tot = 0;
+    MI_HIP(hipMemGetInfo(&fr, &tot));
+    const size_t want = kv_elems * 2 + workspace_estimate(c);
+    if (want > fr) {
+      set_error("KV pool of " + std::to_string(k.num_blocks) + " blocks (" + std::to_string(kv_elems * 2 >> 20) + " MiB over " +
+                std::to_string(k.num_layers) + " layers) + " + std::to_string(workspace_estimate(c) >> 20) +
+                " MiB of workspace do not fit the " + std::to_string(fr >> 20) + " MiB free on the device: lower "
+                "num_gpu_blocks_override / gpu_memory_utilization");
+      return MI_ENOMEM;
+    }
+  }
   MI_TRY(dmalloc(&c->kv_pool, kv_elems, &c->kv_bytes));
   MI_HIP(hipMemsetAsync(c->kv_pool, 0, kv_elems * 2, s));
   // RoPE tables (fp32 angles as HF computes them; llama3 rescale of the inverse frequencies)
@@ -1242,7 +1275,9 @@ int mi_kv_stats(mi_ctx* c, mi_kv_stats_t* o) {
   size_t fr = 0, tot = 0;
   MI_HIP(hipMemGetInfo(&fr, &tot));
   o->kv_bytes = (int64_t)c->kv_bytes; o->weight_bytes = (int64_t)c->weight_bytes;
-  o->workspace_bytes = (int64_t)c->workspace_bytes;
+  // before mi_finalize: what it WILL allocate besides the KV pool (the worker subtracts it from the
+  // free memory it reports to vLLM); afterwards: what it did allocate
+  o->workspace_bytes = c->finalized ? (int64_t)c->workspace_bytes : (int64_t)workspace_estimate(c);
   o->device_free_bytes = (int64_t)fr; o->device_total_bytes = (int64_t)tot;
   o->num_blocks = c->cfg.num_blocks; o->block_size = c->cfg.block_size;
   o->num_kv_heads_local = c->nkv_l; o->head_dim = c->hd; o->num_layers = c->cfg.num_layers;

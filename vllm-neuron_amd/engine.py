@@ -77,11 +77,10 @@ class MI355XEngine:
         if cfg.cache_config.num_gpu_blocks_override is not None:
             num_blocks = cfg.cache_config.num_gpu_blocks_override
         else:
-            # what vLLM does: as many pages as fit in the free memory (x num_layers), capped for
-            # the standalone harness at the minimum the validator demands + the null block
+            # what vLLM does: as many single-layer pages as fit in what the worker reports, capped
+            # for the standalone harness at the minimum the validator demands + the null block
             need = -(-max_model_len // cfg.cache_config.block_size) * max_num_seqs + 1
-            n_layers = hf_config.num_hidden_layers
-            fit = int(self.worker.determine_available_memory() * 0.9) // (spec.page_size_bytes * n_layers)
+            fit = self.worker.determine_available_memory() // spec.page_size_bytes
             num_blocks = max(2, min(fit, need))
         self.worker.initialize_cache(num_blocks, 0)
         self.worker.initialize_from_config(KVCacheConfig(num_blocks=num_blocks))

@@ -95,10 +95,21 @@ class MI355XWorker(WorkerBase):
             torch.set_num_threads(want)
 
     def determine_available_memory(self):
-        """Free device memory after the weights are resident (the reference asks the Neuron
-        runtime and falls back to 20 GiB, neuron_worker.py:51-63)."""
+        """Memory vLLM may turn into KV blocks (the reference asks the Neuron runtime and falls
+        back to 20 GiB, neuron_worker.py:51-63).  vLLM divides this by the page size of the ONE
+        layer `get_kv_cache_spec` advertises, while the pool holds every layer of the model and the
+        library still has its activations / exchange buffers to allocate at `mi_finalize`: so
+        report (free - that workspace - a margin) scaled by one-layer-page / all-layers-block, i.e.
+        the block count vLLM derives is one the pool can really hold."""
         try:
-            return int(self.model_runner.model.model.kv_stats()["device_free_bytes"])
+            native = self.model_runner.model.model
+            st = native.kv_stats()
+            usable = int(st["device_free_bytes"] * 0.95) - int(st["workspace_bytes"])
+            per_block_all_layers = native.kv_bytes_per_block()
+            spec = self.model_runner.get_kv_cache_spec()["layer"]
+            # the spec counts all kv heads of one layer; a shard holds its share of every layer
+            blocks = max(usable, 0) // max(per_block_all_layers, 1)
+            return int(blocks * spec.page_size_bytes)
         except Exception as e:
             logger.debug("Failed to get memory stats: %s", e)
             return 1024 * 1024 * 1024 * 20
