@@ -59,6 +59,8 @@ int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, con
 // M > 16 context-encoding path (MFMA-bound).  x is always bf16 [T, K].
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e,
                 hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+// the wide-N LDS-DMA variant of launch_gemm (1-byte weights); launch_gemm picks it by size
+int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s);
 // M > 16 with FP8 activations: x8 = K-step-major e4m3 image [K / 128][ldx >= T rows][128 B] as
 // launch_rowquant_fp8 writes it (per-token scale in EpiArgs::row_scale), FP8 weights,
 // MX-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate.

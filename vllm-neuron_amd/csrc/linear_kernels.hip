@@ -1183,6 +1183,15 @@ int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, con
 // straight from the pre-tiled global image.
 constexpr int kBM = 128, kBN = 128, kBK = 64;
 
+// XOR swizzle of the 16-byte chunks of a 128-byte activation row in LDS.  A ds_read_b128 is
+// serviced in four groups of 16 lanes ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS); with the
+// fragment addressing of the MFMA B operand (lane (g, c): row c, chunk 2g / 2g+1 for 1-byte weights,
+// g / 4+g for bf16 weights) the plain `chunk ^ (row & 7)` image is conflict-free for the bf16-weight
+// chunk order but puts every group of the 1-byte order two-deep on its banks; folding row bit 3 into
+// the key makes that order conflict-free too (enumerated over the lane groups).
+template <int WD>
+__device__ __forceinline__ int xs_swz(int r) { return WD == MI_W_BF16 ? (r & 7) : ((r & 7) ^ ((r >> 3) & 1)); }
+
 // SPLIT: grid.z K-slices write raw fp32 accumulators to slab[z][m][n] (see gemm_a8_kernel).
 // Registers are kept under 170 per lane so that three work-groups share a CU (the same lesson as
 // the FP8 GEMM): the weight tiles of a K-step are decoded once into their A fragments, the raw
@@ -1241,7 +1250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WD == MI_W_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = srow + 32 * i;
-      *reinterpret_cast<u32x4_t*>(&xs[r * 8 + (sch ^ (r & 7))]) = xr[i];
+      *reinterpret_cast<u32x4_t*>(&xs[r * 8 + (sch ^ xs_swz<WD>(r))]) = xr[i];
     }
     bf16x8_t a0[4], a1[4];
 #pragma unroll
@@ -1264,8 +1273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WD == MI_W_
     for (int mt = 0; mt < 4; ++mt) {
       const int r = wm * 64 + mt * 16 + c;
       const int ch0 = (WD == MI_W_BF16) ? g : 2 * g, ch1 = (WD == MI_W_BF16) ? 4 + g : 2 * g + 1;
-      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch0 ^ (r & 7))]);
-      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch1 ^ (r & 7))]);
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch0 ^ xs_swz<WD>(r))]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xs[r * 8 + (ch1 ^ xs_swz<WD>(r))]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0, acc[i][mt], 0, 0, 0);
@@ -1331,9 +1340,153 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
   return MI_OK;
 }
 
+
+// =====================================================================================
+// GEMM, wide-N tile with an LDS-DMA ring (context encoding at >= 1024 rows, 1-byte weights)
+// =====================================================================================
+// The 128 x 128 kernel above is L1-fill bound: per 64-deep K-step a work-group pulls
+// 16 KiB of bf16 activations + 8 KiB of fp8 weights for 2.1 MFLOP.  Weights are half the bytes per
+// element of the activations, so the tile grows along N: 128 tokens x 256 weight rows = 16 + 16 KiB
+// for 4.2 MFLOP (1.5 x the flops per byte).  Eight waves side by side along N, each 32 weight rows x
+// waves as 2 (tokens) x 4 (weight rows), each 64 x 64 (64 accumulator registers, 12 fragment reads
+// per 32 MFMAs): activation fragments are shared by four waves, weight fragments by two.  Both operands arrive by LDS-DMA
+// (global_load_lds, 1 KiB per wave-instruction: the weight tiles land lane-linear = fragment
+// order; the activation rows land in the XOR-swizzled image of the kernel above, the swizzle being
+// applied to the per-lane SOURCE address) into a ring of three 32 KiB stages: two K-steps are in
+// flight while one is multiplied, retired by a counted vmcnt (4 DMAs per wave and stage) in front of
+// ONE raw barrier per K-step -- no ordinary global load in the loop, so hipcc has nothing to drain.
+constexpr int kWideBM = 128, kWideBN = 256, kWideStage = 32 * 1024, kWideWBytes = 16 * 1024, kWideStages = 3;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int WD, int EPI>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
+                                                        const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
+  static_assert(WD != MI_W_BF16, "1-byte weight tiles (64 k per tile)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int wm = wave & 1, wn = wave >> 1;      // 2 (tokens) x 4 (weight rows) waves, each 64 x 64
+  // XCD-aware tile order (see gemm_a8_kernel): an XCD walks all token blocks of a weight slab back to back
+  const int mtiles = ceil_div(T, kWideBM), ntiles = ceil_div(NT, kWideBN / 16);
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
+  if (nblk >= ntiles) return;
+  const int m0 = mblk * kWideBM, ntb = nblk * (kWideBN / 16);
+  const int nks = K / 64;
+
+  // this lane's DMA sources: wave w brings weight tiles 2w, 2w + 1 of the work-group's 16 (fragment
+  // order) and the 8-row pieces 2w, 2w + 1 of the activation tile
+  const uint4* wsrc[2];
+  const uint16_t* xsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    wsrc[i] = W + (size_t)min(ntb + 2 * wave + i, NT - 1) * KT * 64 + lane;
+    const int r = (2 * wave + i) * 8 + (lane >> 3), sl = lane & 7;
+    xsrc[i] = x + (size_t)min(m0 + r, T - 1) * ldx + ((sl ^ xs_swz<WD>(r)) * 8);   // LDS slot sl of row r holds chunk sl ^ swz(r)
+  }
+  auto issue = [&](int ks) {
+    unsigned char* st = smem + (ks % kWideStages) * kWideStage;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(wsrc[i] + (size_t)ks * 64, st + (2 * wave + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(xsrc[i] + (size_t)ks * 64, st + kWideWBytes + (2 * wave + i) * 1024);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  if (nks > 1) issue(1);
+  for (int ks = 0; ks < nks; ++ks) {
+    // stage ks has landed once at most the 4 DMAs of stage ks + 1 are outstanding (in-order retire)
+    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // every wave's pieces of stage ks are in; everyone is done reading stage ks - 1
+    if (ks + 2 < nks) issue(ks + 2);       // into the buffer stage ks - 1 was read from
+    const unsigned char* st = smem + (ks % kWideStages) * kWideStage;
+    const uint4* xs = reinterpret_cast<const uint4*>(st + kWideWBytes);
+    bf16x8_t b0[4], b1[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r = wm * 64 + mt * 16 + c;
+      b0[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g) ^ xs_swz<WD>(r))]);
+      b1[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g + 1) ^ xs_swz<WD>(r))]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4_t w4 = *reinterpret_cast<const u32x4_t*>(st + (wn * 4 + i) * 1024 + lane * 16);
+      const bf16x8_t a0 = decode8<WD>(w4[0], w4[1]), a1 = decode8<WD>(w4[2], w4[3]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[mt], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[mt], acc[i][mt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nt = ntb + wn * 4 + i;
+    if (nt >= NT) continue;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + c;
+      if (m >= T) continue;
+      epilogue<EPI>(e, m, nt * 16 + g * 4, acc[i][mt]);
+    }
+  }
+}
+
+static int gemm_wide_mode() {   // MI355X_GEMM_WIDE: 0 never, 1 whenever the shape allows, unset: by size
+  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE"); return v ? atoi(v) : -1; }();
+  return m;
+}
+template <int WD>
+static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  const int NT = w.N / 16, KT = w.K / 64;
+  const int mtiles = ceil_div(T, kWideBM), ntiles = ceil_div(w.N, kWideBN);
+  dim3 grid(8 * mtiles * ceil_div(ntiles, 8));
+  const uint4* W = reinterpret_cast<const uint4*>(w.w);
+  constexpr int lds = kWideStages * kWideStage;
+#define MI_GW(EPI_) \
+  do { \
+    MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_>), lds)); \
+    hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e); \
+  } while (0)
+  if (epi == EPI_QKV) MI_GW(EPI_QKV);
+  else if (epi == EPI_SWIGLU) MI_GW(EPI_SWIGLU);
+  else if (epi == EPI_RESID) MI_GW(EPI_RESID);
+  else MI_GW(EPI_F32);
+#undef MI_GW
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+// the wide tile needs 1-byte weights and enough tiles to give every CU one (it runs one work-group per CU)
+static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
+  if (w.wd == MI_W_BF16 || w.K % 64 != 0 || (w.N / 16) < 2) return false;
+  const int mode = gemm_wide_mode();
+  if (forced || mode == 1) return true;
+  if (mode == 0) return false;
+  // measured on the Llama-8B shapes: ahead of the 128 x 128 kernel from the 2048 bucket on (30.9 vs 32.0 ms), behind it
+  // at 1024 (20.2 vs 17.8 ms: 128 / 192-tile grids on a one-work-group-per-CU kernel)
+  return T > 1024 && ceil_div(T, kWideBM) * ceil_div(w.N, kWideBN) >= 256;
+}
+int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");
+  if (w.wd == MI_W_F8E4M3) return launch_gemm_wide_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s);
+  return launch_gemm_wide_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s);
+}
+
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
                 float* splitk_ws, size_t splitk_ws_bytes) {
   MI_CHECK(T >= 1, "gemm: T must be >= 1");
+  if (gemm_wide_wanted(w, T, false) && ldx % 8 == 0) return launch_gemm_wide(w, T, x, ldx, epi, e, s);
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemm: N % 16 == 0 and K % 64 == 0 required");
   MI_CHECK(ldx % 8 == 0, "gemm: x row stride must be a multiple of 8 elements");
   switch (w.wd) {
@@ -1359,7 +1512,8 @@ int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, co
 // through LDS; the next K-step's operands are fetched into registers under the MFMAs.
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 constexpr int kA8BM = 128, kA8BK = 128;   // tile: (64 NTW) weight rows x 128 tokens x 128 K bytes
-constexpr int kA8Pitch = kA8BK + 16;   // LDS row pitch in bytes (+16: rows start 4 banks apart)
+constexpr int kA8Pitch = kA8BK + 32;   // LDS row pitch in bytes: 160 makes the fragment reads (row c, 16 B at g * 16 / + 64) conflict-free
+                                       // over the ds_read_b128 lane groups; 144 left every group two-deep on its banks
 
 // SPLIT: grid.z K-slices each write their raw fp32 accumulators to slab[z][m][n]; splitk_reduce
 // sums the slabs in slice order (deterministic) and applies the epilogue.  Used when a short
@@ -1368,7 +1522,7 @@ template <int EPI, bool SPLIT, int NTW>   // NTW 16-row weight tiles per wave: t
 __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
                                                       const uint8_t* __restrict__ x8, int ldx, EpiArgs e,
                                                       float* __restrict__ slab) {
-  __shared__ __attribute__((aligned(16))) unsigned char xs[kA8BM * kA8Pitch];   // 18 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char xs[kA8BM * kA8Pitch];   // 20 KiB
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
   // XCD-aware tile order.  Work-groups go round-robin over the 8 XCDs (own 4 MiB L2 each), so

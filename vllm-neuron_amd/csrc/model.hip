@@ -1409,6 +1409,7 @@ int mi_op_qlinear(const void* x, int32_t M, const void* w_tiled, const float* sc
   p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = K;
   const bool gemv = force_path == 1 || (force_path == 0 && gemv_fits(M, K));
   if (gemv) return launch_gemv(W, M, PRO_BF16, p, EPI_F32, e, (hipStream_t)stream);
+  if (force_path == 3) return launch_gemm_wide(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
   return launch_gemm(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
 }
 int mi_op_qlinear_a8(const void* x, int32_t M, const void* w_tiled, const float* scale, const float* bias, int32_t N,
