@@ -1355,67 +1355,80 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
 // applied to the per-lane SOURCE address) into a ring of three 32 KiB stages: two K-steps are in
 // flight while one is multiplied, retired by a counted vmcnt (4 DMAs per wave and stage) in front of
 // ONE raw barrier per K-step -- no ordinary global load in the loop, so hipcc has nothing to drain.
-constexpr int kWideBM = 128, kWideBN = 256, kWideStage = 32 * 1024, kWideWBytes = 16 * 1024, kWideStages = 3;
+constexpr int kWideBN = 256, kWideWBytes = 16 * 1024, kWideStages = 3;
 
 __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int WD, int EPI>
+// BM = 128: waves 2 (tokens) x 4 (weight rows), each 64 x 64.  BM = 256: each 128 x 64 (128 accumulator
+// registers): 16 + 32 KiB per K-step for 8.4 MFLOP -- the kernel is bound by what a CU can take in
+// (~25 GB/s: a K-step's bytes over its loaded latency), so fewer bytes per flop is the lever.
+template <int WD, int EPI, int BM>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
                                                         const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
   static_assert(WD != MI_W_BF16, "1-byte weight tiles (64 k per tile)");
+  static_assert(BM == 128 || BM == 256, "token block");
+  constexpr int MT = BM / 32;                 // 16-token tiles per wave
+  constexpr int XP = BM / 64;                 // 8-row activation pieces per wave and stage
+  constexpr int kStage = kWideWBytes + BM * 128;
+  constexpr int kDma = 2 + XP;                // DMAs per wave and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int wm = wave & 1, wn = wave >> 1;      // 2 (tokens) x 4 (weight rows) waves, each 64 x 64
+  const int wm = wave & 1, wn = wave >> 1;
   // XCD-aware tile order (see gemm_a8_kernel): an XCD walks all token blocks of a weight slab back to back
-  const int mtiles = ceil_div(T, kWideBM), ntiles = ceil_div(NT, kWideBN / 16);
+  const int mtiles = ceil_div(T, BM), ntiles = ceil_div(NT, kWideBN / 16);
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
   const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
   if (nblk >= ntiles) return;
-  const int m0 = mblk * kWideBM, ntb = nblk * (kWideBN / 16);
+  const int m0 = mblk * BM, ntb = nblk * (kWideBN / 16);
   const int nks = K / 64;
 
   // this lane's DMA sources: wave w brings weight tiles 2w, 2w + 1 of the work-group's 16 (fragment
-  // order) and the 8-row pieces 2w, 2w + 1 of the activation tile
+  // order) and XP 8-row pieces of the activation tile
   const uint4* wsrc[2];
-  const uint16_t* xsrc[2];
+  const uint16_t* xsrc[XP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    wsrc[i] = W + (size_t)min(ntb + 2 * wave + i, NT - 1) * KT * 64 + lane;
-    const int r = (2 * wave + i) * 8 + (lane >> 3), sl = lane & 7;
+  for (int i = 0; i < 2; ++i) wsrc[i] = W + (size_t)min(ntb + 2 * wave + i, NT - 1) * KT * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int r = (XP * wave + i) * 8 + (lane >> 3), sl = lane & 7;
     xsrc[i] = x + (size_t)min(m0 + r, T - 1) * ldx + ((sl ^ xs_swz<WD>(r)) * 8);   // LDS slot sl of row r holds chunk sl ^ swz(r)
   }
   auto issue = [&](int ks) {
-    unsigned char* st = smem + (ks % kWideStages) * kWideStage;
+    unsigned char* st = smem + (ks % kWideStages) * kStage;
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(wsrc[i] + (size_t)ks * 64, st + (2 * wave + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(xsrc[i] + (size_t)ks * 64, st + kWideWBytes + (2 * wave + i) * 1024);
+    for (int i = 0; i < XP; ++i) glds16(xsrc[i] + (size_t)ks * 64, st + kWideWBytes + (XP * wave + i) * 1024);
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][MT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   issue(0);
   if (nks > 1) issue(1);
   for (int ks = 0; ks < nks; ++ks) {
-    // stage ks has landed once at most the 4 DMAs of stage ks + 1 are outstanding (in-order retire)
-    if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage ks has landed once at most the DMAs of stage ks + 1 are outstanding (in-order retire)
+    if (ks + 1 < nks) {
+      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();          // every wave's pieces of stage ks are in; everyone is done reading stage ks - 1
     if (ks + 2 < nks) issue(ks + 2);       // into the buffer stage ks - 1 was read from
-    const unsigned char* st = smem + (ks % kWideStages) * kWideStage;
+    const unsigned char* st = smem + (ks % kWideStages) * kStage;
     const uint4* xs = reinterpret_cast<const uint4*>(st + kWideWBytes);
-    bf16x8_t b0[4], b1[4];
+    bf16x8_t b0[MT], b1[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int r = wm * 64 + mt * 16 + c;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int r = wm * (BM / 2) + mt * 16 + c;
       b0[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g) ^ xs_swz<WD>(r))]);
       b1[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g + 1) ^ xs_swz<WD>(r))]);
     }
@@ -1424,7 +1437,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict_
       const u32x4_t w4 = *reinterpret_cast<const u32x4_t*>(st + (wn * 4 + i) * 1024 + lane * 16);
       const bf16x8_t a0 = decode8<WD>(w4[0], w4[1]), a1 = decode8<WD>(w4[2], w4[3]);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[mt], acc[i][mt], 0, 0, 0);
         acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[mt], acc[i][mt], 0, 0, 0);
       }
@@ -1435,8 +1448,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict_
     const int nt = ntb + wn * 4 + i;
     if (nt >= NT) continue;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wm * 64 + mt * 16 + c;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + wm * (BM / 2) + mt * 16 + c;
       if (m >= T) continue;
       epilogue<EPI>(e, m, nt * 16 + g * 4, acc[i][mt]);
     }
@@ -1447,17 +1460,21 @@ static int gemm_wide_mode() {   // MI355X_GEMM_WIDE: 0 never, 1 whenever the sha
   static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE"); return v ? atoi(v) : -1; }();
   return m;
 }
-template <int WD>
-static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+static int gemm_wide_bm() {      // MI355X_GEMM_WIDE_BM: 128 / 256 forces the token block (default: by grid size)
+  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE_BM"); return v ? atoi(v) : 0; }();
+  return m;
+}
+template <int WD, int BM>
+static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
   const int NT = w.N / 16, KT = w.K / 64;
-  const int mtiles = ceil_div(T, kWideBM), ntiles = ceil_div(w.N, kWideBN);
+  const int mtiles = ceil_div(T, BM), ntiles = ceil_div(w.N, kWideBN);
   dim3 grid(8 * mtiles * ceil_div(ntiles, 8));
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
-  constexpr int lds = kWideStages * kWideStage;
+  constexpr int lds = kWideStages * (kWideWBytes + BM * 128);
 #define MI_GW(EPI_) \
   do { \
-    MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_>), lds)); \
-    hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e); \
+    MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_, BM>), lds)); \
+    hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_, BM>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e); \
   } while (0)
   if (epi == EPI_QKV) MI_GW(EPI_QKV);
   else if (epi == EPI_SWIGLU) MI_GW(EPI_SWIGLU);
@@ -1467,6 +1484,15 @@ static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int l
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
+template <int WD>
+static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+  // 256-token blocks when that still gives every CU at least two work-groups to walk (the grid
+  // is one resident wave of work-groups per CU at a time)
+  const int forced = gemm_wide_bm();
+  const bool big = forced ? forced == 256 : ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512;
+  if (big) return launch_gemm_wide_bm<WD, 256>(w, T, x, ldx, epi, e, s);
+  return launch_gemm_wide_bm<WD, 128>(w, T, x, ldx, epi, e, s);
+}
 // the wide tile needs 1-byte weights and enough tiles to give every CU one (it runs one work-group per CU)
 static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
   if (w.wd == MI_W_BF16 || w.K % 64 != 0 || (w.N / 16) < 2) return false;
@@ -1475,7 +1501,7 @@ static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
   if (mode == 0) return false;
   // measured on the Llama-8B shapes: ahead of the 128 x 128 kernel from the 2048 bucket on (30.9 vs 32.0 ms), behind it
   // at 1024 (20.2 vs 17.8 ms: 128 / 192-tile grids on a one-work-group-per-CU kernel)
-  return T > 1024 && ceil_div(T, kWideBM) * ceil_div(w.N, kWideBN) >= 256;
+  return T > 1024 && ceil_div(T, 128) * ceil_div(w.N, kWideBN) >= 256;
 }
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
   MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");
