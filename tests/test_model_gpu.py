@@ -243,3 +243,54 @@ def test_in_launch_attention_merge_matches_oracle():
                         "quantized_matches_oracle or bf16_matches_hf_golden"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name,wd", [("llama31_like", "f8e4m3"), ("tinyllama_like", "bf16")])
+def test_block_size_16_matches_oracle(name, wd):
+    """vLLM's default block size: a 32-token attention tile then spans two blocks (each 16-token half
+    looks its own block up).  Scattered blocks, a prefix hit on a 16-token boundary, batched decode
+    across block boundaries."""
+    from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+    from tests.helpers import decode_inputs, prefill_inputs
+    bs, maxlen, nseq = 16, 256, 4
+    mb = maxlen // bs
+    nb = 1 + nseq * mb
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=1)
+    qt = "per_channel_symmetric"
+    quant = None if wd == "bf16" else dict(quantized=True, quantization_dtype=wd, quantization_type=qt)
+    oracle = PagedDecoderOracle(cfg, w, nb, bs, compute="bf16", quant=quant)
+    rs = cfg.rope_scaling or {}
+    model = NativeModel(
+        num_layers=cfg.num_layers, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads,
+        head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size, vocab_size=cfg.vocab_size,
+        rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, rope_type=1 if rs else 0,
+        rope_factor=rs.get("factor", 1.0), rope_low_freq_factor=rs.get("low_freq_factor", 1.0),
+        rope_high_freq_factor=rs.get("high_freq_factor", 4.0),
+        rope_original_max_position=rs.get("original_max_position_embeddings", 0), qkv_bias=int(cfg.qkv_bias),
+        tie_word_embeddings=int(cfg.tie_word_embeddings), num_blocks=nb, block_size=bs, max_num_seqs=nseq,
+        max_model_len=maxlen, weight_dtype=MI_W[wd], quant_type=MI_Q[qt], quantize_lm_head=1, tp_degree=1, tp_rank=0,
+        device_id=0, use_graphs=1)
+    model.load_state_dict(w)
+    model.finalize()
+    g = torch.Generator().manual_seed(5)
+    perm = (torch.randperm(nb - 1, generator=g) + 1).tolist()
+    blocks = [perm[i * mb:(i + 1) * mb] for i in range(nseq)]
+    lens = (15, 16, 47, 130)
+    seqs = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in lens]
+    seqs[2][:32] = seqs[3][:32]                         # two shared 16-token blocks
+    blocks[2][:2] = blocks[3][:2]
+    worst = 0.0
+    for i in (3, 0, 1, 2):
+        inp = prefill_inputs(seqs[i], blocks[i], bs, maxlen, 32 if i == 2 else 0)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got - ref).abs().max().item())
+        seqs[i].append(int(ref.argmax()))
+    for _ in range(20):                                 # crosses 16- and 32-token boundaries for every row
+        inp = decode_inputs([s[-1] for s in seqs], [len(s) - 1 for s in seqs], blocks, bs, maxlen)
+        got, ref = model.forward(**inp), oracle.forward(**inp)
+        worst = max(worst, (got - ref).abs().max().item())
+        for s, row in zip(seqs, ref):
+            s.append(int(row.argmax()))
+    assert worst < 0.06, worst
+    model.close()

@@ -81,24 +81,36 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
   uint16_t* Vw = Vs + wave * VT;
 
   u32x4_t kA[2 * KS], vA[NV], kB[2 * KS], vB[NV];
+  // A 32-token tile is two 16-token halves; with block_size 16 (vLLM's default) they sit in two
+  // different blocks, so each half looks its own block up (the same block for block_size % 32 == 0).
   auto issue = [&](u32x4_t (&kr)[2 * KS], u32x4_t (&vr)[NV], int tt) {
     const bool live = tt < t_end;
     const int tok0 = live ? tt * 32 : 0;
-    const int blk = live ? block_table[(size_t)b * MB + tok0 / bs] : 0;
-    const size_t row0 = live ? ((size_t)blk * nkv + kvh) * bs + (tok0 % bs) : 0;
-    // K fragment (u, ks): token 16u + c, dims 32 ks + 8 g ..
-    const size_t kbase = live ? (row0 + c) * HD + g * 8 : 0;
-    const size_t ku = live ? (size_t)16 * HD : 0, kk = live ? 32 : 0;
+    size_t rowh[2];   // pool row of the first token of each half
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u) {
+      // the second half of the last tile may lie beyond the context (and beyond the table): masked by score, read from the null block
+      const bool in = live && (tok0 + 16 * u) < ctx;
+      const int blk = in ? block_table[(size_t)b * MB + (tok0 + 16 * u) / bs] : 0;
+      rowh[u] = in ? ((size_t)blk * nkv + kvh) * bs + ((tok0 + 16 * u) % bs) : 0;
+    }
+    // K fragment (u, ks): token 16u + c, dims 32 ks + 8 g ..
+    const size_t kk = live ? 32 : 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t kbase = live ? (rowh[u] + c) * HD + g * 8 : 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        kr[u * KS + ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kpool + kbase + u * ku + ks * kk));
-    // V rows: lane-linear 16-byte chunks (whole rows per instruction)
-    const size_t vbase = live ? row0 * HD + lane * 8 : 0;
-    const size_t vi = live ? 64 * 8 : 0;
+        kr[u * KS + ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kpool + kbase + ks * kk));
+    }
+    // V rows: lane-linear 16-byte chunks (whole rows per instruction); load i covers rows
+    // [i * 64 / CPR, (i + 1) * 64 / CPR) of the tile, i.e. half (i * 64 / CPR) / 16
 #pragma unroll
-    for (int i = 0; i < NV; ++i) vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vpool + vbase + i * vi));
+    for (int i = 0; i < NV; ++i) {
+      const int row = (lane + 64 * i) / CPR, ch = (lane + 64 * i) % CPR;   // row of the tile, 16-byte chunk of the row
+      const size_t src = live ? (rowh[row >> 4] + (row & 15)) * HD + ch * 8 : 0;
+      vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vpool + src));
+    }
   };
   issue(kA, vA, t_beg + wave);
 
@@ -368,7 +380,7 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
                        int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
   MI_CHECK(nh % nkv == 0 && nh / nkv <= 16, "attention: q heads per kv head must be 1..16");
-  MI_CHECK(block_size % 32 == 0, "attention: block_size must be a multiple of 32");
+  MI_CHECK(block_size % 16 == 0, "attention: block_size must be a multiple of 16");
   if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
   return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
 }

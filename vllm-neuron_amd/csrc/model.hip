@@ -540,7 +540,7 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   MI_CHECK(k.num_heads % k.tp_degree == 0, "num_heads must divide by tp_degree");
   MI_CHECK(k.num_heads % k.num_kv_heads == 0, "num_heads must be a multiple of num_kv_heads");
   MI_CHECK(k.intermediate_size % k.tp_degree == 0 && k.vocab_size % k.tp_degree == 0, "intermediate/vocab must divide by tp_degree");
-  MI_CHECK(k.block_size > 0 && k.block_size % 32 == 0, "block_size must be a positive multiple of 32");
+  MI_CHECK(k.block_size > 0 && k.block_size % 16 == 0, "block_size must be a positive multiple of 16");
   MI_CHECK(k.num_blocks >= 2, "num_blocks must include the null block and at least one real block");
   // token-generation batches of up to 16 rows stream the weights (GEMV); larger ones take the
   // context-encoding GEMMs (vLLM's default max_num_seqs for this platform is 32, platform.py)
