@@ -855,6 +855,7 @@ int mi_finalize(mi_ctx* c) {
   if (c->owned_group) {
     MI_CHECK(!c->finalized, "bad state");
     MI_TRY(group_run(c->owned_group, [&](mi_ctx* rc, int) { return mi_finalize(rc); }));
+    MI_TRY(group_selftest(c->owned_group));
     c->finalized = true;
     return MI_OK;
   }

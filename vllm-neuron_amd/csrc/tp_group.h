@@ -95,6 +95,8 @@ void group_destroy(mi_group* g);
 int group_alloc_exchange(mi_ctx* c);
 // sum `count` fp32 values of `buf` over the ranks, in place, on c->stream (called from rank r's thread)
 int group_all_reduce(mi_ctx* c, float* buf, size_t count);
+// one exchange on known data after the buffers exist; falls back to RCCL when the peer-memory path fails it
+int group_selftest(mi_group* g);
 // device-side error word of rank c (nonzero: an exchange kernel gave up waiting)
 int group_check_errors(mi_ctx* c);
 

@@ -10,6 +10,12 @@
 
 extern "C" const char* mi_last_error(void);
 
+#define MI_TRY(expr)              \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != MI_OK) return _rc; \
+  } while (0)
+
 namespace mi {
 
 // =====================================================================================
@@ -76,7 +82,7 @@ __device__ __forceinline__ void wait_flags(const uint32_t* flags, int T, int sel
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: drop stale lines of the peers' buffers
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope, every wave: drop stale lines of the peers' buffers
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(kArThreads) void ar_reduce_kernel(float* __restrict
       }
     }
     __syncthreads();
-    if (t == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope, every wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -396,13 +402,18 @@ void group_destroy(mi_group* g) {
   delete g;
 }
 
-static int alloc_exchange_mem(void** p, size_t bytes) {
-  // uncached: a peer's loads must come from this GPU's memory, not from a cache line of an earlier epoch
-  hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
-  if (e != hipSuccess) {
+// Flag blocks are UNCACHED device memory: a peer's polling loads and the publisher's flag stores
+// must meet in this GPU's memory.  The message slots are ordinary device memory, kept coherent by
+// the release (write back L2) in front of the flag store and the acquire (drop non-local lines)
+// behind the flag wait.  Uncached slots were tried and dropped: on one GPU the FIRST exchange after
+// the allocation read zeros for 8 KiB..64 KiB of the peers' slots in about one process in six
+// (profiles/README.md, "exchange self-test"); ordinary memory never did in the same loop.
+static int alloc_exchange_mem(void** p, size_t bytes, bool uncached) {
+  if (uncached && !getenv("MI355X_TP_FLAGS_CACHED")) {
+    if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess) return MI_OK;
     (void)hipGetLastError();
-    MI_HIP(hipMalloc(p, bytes));
   }
+  MI_HIP(hipMalloc(p, bytes));
   return MI_OK;
 }
 
@@ -413,11 +424,11 @@ int group_alloc_exchange(mi_ctx* c) {
     const size_t cap = (size_t)c->max_rows * c->H;
     const size_t ycap = ((cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
     void *xb = nullptr, *yb = nullptr, *f1 = nullptr, *f2 = nullptr, *ct = nullptr;
-    if (alloc_exchange_mem(&xb, 2 * cap * 4) != MI_OK) return MI_EHIP;   // two slots, fp32-sized (token generation sends fp32)
-    if (alloc_exchange_mem(&yb, 2 * ycap * 2) != MI_OK) return MI_EHIP;
+    if (alloc_exchange_mem(&xb, 2 * cap * 4, false) != MI_OK) return MI_EHIP;   // two slots, fp32-sized (token generation sends fp32)
+    if (alloc_exchange_mem(&yb, 2 * ycap * 2, false) != MI_OK) return MI_EHIP;
     const size_t fbytes = (size_t)T * kArMaxBlocks * 4;
-    if (alloc_exchange_mem(&f1, fbytes) != MI_OK) return MI_EHIP;
-    if (alloc_exchange_mem(&f2, fbytes) != MI_OK) return MI_EHIP;
+    if (alloc_exchange_mem(&f1, fbytes, true) != MI_OK) return MI_EHIP;
+    if (alloc_exchange_mem(&f2, fbytes, true) != MI_OK) return MI_EHIP;
     MI_HIP(hipMalloc(&ct, AR_WORDS * 4));
     MI_HIP(hipMemsetAsync(f1, 0, fbytes, c->stream));
     MI_HIP(hipMemsetAsync(f2, 0, fbytes, c->stream));
@@ -474,6 +485,90 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
   }
   MI_HIP(hipGetLastError());
   return MI_OK;
+}
+
+// One exchange on known data, checked on the host: rank r contributes r + 1 (+ a per-element
+// ramp), every rank must end with the same exact sums.  Run once after the exchange buffers
+// exist; the caller falls back to RCCL when the peer-memory path does not deliver (a fabric /
+// driver configuration this code has never met), instead of failing at the first model call.
+static int selftest_rank(mi_ctx* c, size_t n) {
+  mi_group* g = c->grp;
+  const int T = g->T, r = c->cfg.tp_rank;
+  // PINNED staging + copies on the shard's own stream: a copy from pageable memory is staged by the
+  // runtime outside the order of a non-blocking stream (seen: its tail landing behind the reduce and
+  // restoring the rank's own input from the second page on)
+  float* h = nullptr;
+  MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), n * 4, hipHostMallocDefault));
+  for (size_t i = 0; i < n; ++i) h[i] = (float)(r + 1) + (float)(i % 61) * 0.25f;   // exact in bf16 too
+  int rc = MI_OK;
+  if (hipMemcpyAsync(c->partial, h, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = MI_EHIP;
+  if (rc == MI_OK) rc = group_all_reduce(c, c->partial, n);
+  if (rc == MI_OK && hipMemcpyAsync(h, c->partial, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = MI_EHIP;
+  if (rc == MI_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = MI_EHIP;
+  if (rc == MI_OK) rc = group_check_errors(c);
+  if (rc != MI_OK) {
+    hipHostFree(h);
+    if (rc == MI_EHIP) set_error("tensor-parallel exchange self-test: HIP copy failed");
+    return rc;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const float want = (float)(T * (T + 1) / 2) + (float)T * (float)(i % 61) * 0.25f;
+    if (h[i] != want) {
+      std::string dbg;
+      if (!g->use_rccl) {
+        uint32_t ep = 0;
+        (void)hipMemcpy(&ep, g->counters[r] + AR_EPOCH_PUB, 4, hipMemcpyDeviceToHost);
+        dbg = " epoch " + std::to_string(ep) + " peers:";
+        for (int p = 0; p < T; ++p) {
+          float v[2] = {-1.f, -1.f};
+          (void)hipMemcpy(v, reinterpret_cast<const unsigned char*>(g->peers.xbuf[p]) + (size_t)(ep & 1) * g->cap * 4 + i * 4, 4, hipMemcpyDeviceToHost);
+          (void)hipMemcpy(v + 1, reinterpret_cast<const unsigned char*>(g->peers.xbuf[p]) + (size_t)((ep + 1) & 1) * g->cap * 4 + i * 4, 4, hipMemcpyDeviceToHost);
+          dbg += " " + std::to_string(v[0]) + "/" + std::to_string(v[1]);
+        }
+        size_t bad = 0, last = i;
+        for (size_t j = i; j < n; ++j) if (h[j] != (float)(T * (T + 1) / 2) + (float)T * (float)(j % 61) * 0.25f) { ++bad; last = j; }
+        dbg += " bad " + std::to_string(bad) + " last " + std::to_string(last) + " cap " + std::to_string(g->cap);
+      }
+      set_error("tensor-parallel exchange self-test (" + std::to_string(n) + " elements): rank " + std::to_string(r) +
+                " element " + std::to_string(i) + " is " + std::to_string(h[i]) + ", expected " + std::to_string(want) + dbg);
+      hipHostFree(h);
+      return MI_ECOMM;
+    }
+  }
+  hipHostFree(h);
+  return MI_OK;
+}
+
+int group_selftest(mi_group* g) {
+  auto run = [&]() {
+    // a token-generation sized message (one-shot) and, when the slots allow, a context-encoding sized one (two-shot)
+    int rc = MI_OK;
+    const int iters = getenv("MI355X_ST_ITERS") ? atoi(getenv("MI355X_ST_ITERS")) : 2;   // both slots of the double buffer
+    for (int it = 0; it < iters && rc == MI_OK; ++it) {
+      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->use_rccl ? (size_t)c->max_rows * c->H : g->cap, 4 * 4096)); });
+      if (rc != MI_OK) fprintf(stderr, "[mi355x] self-test failed at iteration %d\n", it);
+    }
+    if (rc == MI_OK && !g->use_rccl && g->cap >= kArTwoShotBytes)
+      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->cap, kArTwoShotBytes) / 8 * 8); });
+    return rc;
+  };
+  int rc = run();
+  if (rc == MI_OK || g->use_rccl || g->lockstep) return rc;
+  // the peer-memory exchange did not deliver on this machine: RCCL instead
+  fprintf(stderr, "[mi355x] tensor-parallel exchange over peer memory failed its self-test (%s); falling back to RCCL\n",
+          mi_last_error());
+  std::vector<ncclComm_t> comms(g->T);
+  std::vector<int> devs;
+  for (int r = 0; r < g->T; ++r) devs.push_back(g->ranks[r]->cfg.device_id);
+  ncclResult_t nr = ncclCommInitAll(comms.data(), g->T, devs.data());
+  if (nr != ncclSuccess) {
+    set_error(std::string("peer-memory exchange failed its self-test and ncclCommInitAll failed too: ") + ncclGetErrorString(nr));
+    return MI_ECOMM;
+  }
+  for (int r = 0; r < g->T; ++r) g->ranks[r]->comm = comms[r];
+  g->use_rccl = 1;
+  g->bar->reset();
+  return run();
 }
 
 int group_check_errors(mi_ctx* c) {
