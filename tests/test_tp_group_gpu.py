@@ -80,8 +80,13 @@ def test_exchange_kernels_follow_the_stated_rule(tp):
 
 # llama31_like: 8 q / 2 kv heads -> 4 + 1 per rank at TP 2.  tinyllama_like: 8 q heads on ONE kv
 # head -> at TP 4 every rank holds 2 q heads and a replica of the kv head (the reference skips
-# vLLM's divisibility check for exactly this case, platform.py:58-64).
+# vLLM's divisibility check for exactly this case, platform.py:58-64).  qwen25_like: 7 q heads on one kv
+# head (Qwen2.5-7B's 28 / 4 ratio) do not divide: TP 2 = 4 + (3 + 1 zero-weight padding head), TP 4 =
+# 2 + 2 + 2 + (1 + 1 padding); with qkv biases.
 @pytest.mark.parametrize("name,tp,weight_dtype,quant_type", [
+    ("qwen25_like", 2, "int8", "per_channel_symmetric"),
+    ("qwen25_like", 4, "bf16", "per_tensor_symmetric"),
+    ("qwen25_like", 4, "f8e4m3", "per_tensor_symmetric"),
     ("llama31_like", 2, "bf16", "per_tensor_symmetric"),
     ("llama31_like", 2, "f8e4m3", "per_channel_symmetric"),
     ("tinyllama_like", 4, "f8e4m3", "per_channel_symmetric"),
@@ -192,3 +197,56 @@ def test_llama33_70b_tp8_properties_and_tp1_agreement():
         x = drift(a[key], b[key])
         print(f"70B TP8 vs TP1 [{key}]: {x}")
         assert x[0] <= 0.14 and x[1] <= 0.7 and x[2] > 0.98, (key, x)
+
+
+# ---- Qwen2.5-7B INT8 at TP 8: 28 q heads on 4 kv heads do not divide by 8 ------------------------------
+QWEN25_7B = dict(num_layers=28, hidden_size=3584, num_heads=28, num_kv_heads=4, head_dim=128,
+                 intermediate_size=18944, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                 rope_type=0, qkv_bias=1, tie_word_embeddings=0)
+
+
+def _qwen7b(tp):
+    from vllm_neuron_amd._native import MI_Q, MI_TP_ALL_RANKS, MI_W, NativeModel
+    m = NativeModel(**QWEN25_7B, num_blocks=F_NB, block_size=F_BS, max_num_seqs=F_NSEQ, max_model_len=F_MAXLEN,
+                    weight_dtype=MI_W["int8"], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
+                    tp_degree=tp, tp_rank=MI_TP_ALL_RANKS if tp > 1 else 0, tp_device_ids=[0] * tp, device_id=0,
+                    use_graphs=1, ctx_buckets=[256, 512, 1024, 2048], prefill_fp8_activations=0)
+    m.init_synthetic_weights(1, 0.02)
+    m.finalize()
+    return m
+
+
+def test_qwen25_7b_tp8_padded_heads_against_tp1():
+    """The reference runs head counts that do not divide by the TP degree (it skips vLLM's check,
+    /root/reference/vllm_neuron/platform.py:58-64).  Here: every kv head on 2 ranks, its 7 q heads
+    dealt 4 + 3 with one zero-weight padding head -- the real Qwen2.5-7B shapes, all 28 layers."""
+    g = torch.Generator().manual_seed(6)
+    p = torch.randint(0, 152064, (200,), generator=g).tolist()
+    blocks = (torch.randperm(F_NB - 1, generator=g) + 1).tolist()
+    rows = [blocks[i * F_MB:(i + 1) * F_MB] for i in range(F_NSEQ)]
+
+    def run(m):
+        out = {"full": m.forward(**prefill_inputs(p, rows[0], F_BS, F_MAXLEN, 0))}
+        m.forward(**prefill_inputs(p[:-1], rows[1], F_BS, F_MAXLEN, 0))
+        inp = decode_inputs([p[-1]], [len(p) - 1], [rows[1]], F_BS, F_MAXLEN)
+        out["step"] = m.forward(**inp)
+        out["ids"] = m.forward_tokens(**inp).tolist()
+        return out
+
+    m8 = _qwen7b(8)
+    a = run(m8)
+    st = m8.kv_stats()
+    m8.close()
+    assert st["num_kv_heads_local"] == 1, st
+    m1 = _qwen7b(1)
+    b = run(m1)
+    m1.close()
+    std = b["full"].std().item()
+    assert torch.isfinite(a["full"]).all() and std > 0.1
+    assert a["ids"] == a["step"].argmax(dim=1).tolist()
+    for key in ("full", "step"):
+        d = (a[key] - b[key]).float()
+        rms, mx = d.pow(2).mean().sqrt().item() / std, d.abs().max().item() / std
+        cos = torch.nn.functional.cosine_similarity(a[key].float(), b[key].float()).min().item()
+        print(f"Qwen2.5-7B TP8 vs TP1 [{key}]: rms/std {rms:.4f} max/std {mx:.3f} cos {cos:.4f}")
+        assert rms <= 0.06 and mx <= 0.35 and cos > 0.995, (key, rms, mx, cos)

@@ -89,6 +89,9 @@ struct QuantJob {
   float* dst_scale;    // [dstN]
   float* tmp_rowmax;   // [src_rows_total + 1] scratch
   int src_rows_total;  // rows of the full tensor (per-tensor scale spans all of them)
+  // zero padding (q heads a rank holds only as padding, model.hip): the LAST pad_rows of the n_rows taken and
+  // the LAST pad_cols of the K columns taken are not read from the source: zeros (padding rows: scale 1)
+  int pad_rows, pad_cols;
 };
 int run_quant_job(const QuantJob& j, hipStream_t s);
 int launch_untile(const void* tiled, int N, int K, int wd, void* out, hipStream_t s);

@@ -1501,7 +1501,13 @@ static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
   if (mode == 0) return false;
   // measured on the Llama-8B shapes: ahead of the 128 x 128 kernel from the 2048 bucket on (30.9 vs 32.0 ms), behind it
   // at 1024 (20.2 vs 17.8 ms: 128 / 192-tile grids on a one-work-group-per-CU kernel)
-  return T > 1024 && ceil_div(T, 128) * ceil_div(w.N, kWideBN) >= 256;
+  // and only where its one-work-group-per-CU grid fills whole rounds of the chip: QKV at 2048 tokens (N 6144) is 384
+  // work-groups = 1.5 rounds, 144.7 us against 118.2 us on the 128 x 128 kernel (768 work-groups of 256 threads)
+  if (T <= 1024) return false;
+  int cus = 256;
+  if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
+  const int wgs = ceil_div(T, 128) * ceil_div(w.N, kWideBN);
+  return wgs >= cus && wgs * 5 >= ceil_div(wgs, cus) * cus * 4;
 }
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
   MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");
@@ -1840,9 +1846,26 @@ __global__ __launch_bounds__(256) void quant_tile_kernel(QuantJob j, int nt_lo, 
   const int r = nt * 16 + (lane & 15), gq = lane >> 4;
   const int i = dst_to_src_row(j, r);
   if (i < 0) return;
-  const int srow = j.src_row0 + i;
   constexpr int EPL = (WD == MI_W_BF16) ? 8 : 16;  // elements per lane
-  const float* src = j.src + (size_t)srow * j.ld + j.src_col0 + kt * (EPL * 4) + gq * EPL;
+  const int col0 = kt * (EPL * 4) + gq * EPL;      // first of the lane's columns, relative to src_col0
+  const bool pad_row = i >= j.n_rows - j.pad_rows;
+  const int k_src = j.K - j.pad_cols;
+  if (pad_row || col0 >= k_src) {                  // EPL divides every head size: a lane is all padding or none
+    if (pad_row && kt == 0 && gq == 0) j.dst_scale[r] = 1.f;
+    if (!pad_row && kt == 0 && gq == 0) {
+      float sc = 1.f;
+      if constexpr (WD != MI_W_BF16) {
+        const float qm = (WD == MI_W_INT8) ? 127.f : 448.f;
+        const float am = (j.quant_type == MI_Q_PER_TENSOR_SYMMETRIC) ? j.tmp_rowmax[j.src_rows_total] : j.tmp_rowmax[j.src_row0 + i];
+        sc = am > 0.f ? am / qm : 1.f;
+      }
+      j.dst_scale[r] = sc;
+    }
+    reinterpret_cast<uint4*>(j.dst)[((size_t)nt * KT + kt) * 64 + lane] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const int srow = j.src_row0 + i;
+  const float* src = j.src + (size_t)srow * j.ld + j.src_col0 + col0;
   float scale = 1.f;
   if constexpr (WD != MI_W_BF16) {
     const float qmax = (WD == MI_W_INT8) ? 127.f : 448.f;

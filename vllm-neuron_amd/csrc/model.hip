@@ -371,8 +371,9 @@ int ensure_stage(mi_ctx* c, size_t elems, int rows) {
 
 // src: fp32 [rows_total, ld] on the device (the FULL HF tensor)
 int place_matrix(mi_ctx* c, Linear& L, const float* src, int rows_total, int ld, int src_row0, int n_rows,
-                 int src_col0, int rowmap, int dst_row0) {
+                 int src_col0, int rowmap, int dst_row0, int pad_rows = 0, int pad_cols = 0) {
   QuantJob j{};
+  j.pad_rows = pad_rows; j.pad_cols = pad_cols;
   j.src = src; j.ld = ld; j.src_row0 = src_row0; j.src_col0 = src_col0; j.n_rows = n_rows; j.K = L.K;
   j.rowmap = rowmap; j.hd = c->hd; j.dst_row0 = dst_row0; j.wd = L.wd; j.quant_type = c->cfg.quant_type;
   j.dst = L.w; j.dst_scale = L.scale; j.tmp_rowmax = c->rowmax; j.src_rows_total = rows_total;
@@ -410,7 +411,7 @@ int route_matrix(mi_ctx* c, const std::string& name, const float* dsrc, int rows
   const int I = k.intermediate_size;
   if (ends_with(name, "self_attn.q_proj.weight")) {
     MI_CHECK(rows == k.num_heads * c->hd && cols == c->H, "q_proj shape");
-    return place_matrix(c, W.qkv, dsrc, rows, cols, r * c->q_dim, c->q_dim, 0, ROWMAP_ROPE_PAIRS, 0);
+    return place_matrix(c, W.qkv, dsrc, rows, cols, c->qh0 * c->hd, c->q_dim, 0, ROWMAP_ROPE_PAIRS, 0, (c->nh_l - c->nh_real) * c->hd, 0);
   }
   if (ends_with(name, "self_attn.k_proj.weight")) {
     MI_CHECK(rows == k.num_kv_heads * c->hd && cols == c->H, "k_proj shape");
@@ -422,7 +423,7 @@ int route_matrix(mi_ctx* c, const std::string& name, const float* dsrc, int rows
   }
   if (ends_with(name, "self_attn.o_proj.weight")) {
     MI_CHECK(rows == c->H && cols == k.num_heads * c->hd, "o_proj shape");
-    return place_matrix(c, W.o, dsrc, rows, cols, 0, c->H, r * c->q_dim, ROWMAP_PLAIN, 0);
+    return place_matrix(c, W.o, dsrc, rows, cols, 0, c->H, c->qh0 * c->hd, ROWMAP_PLAIN, 0, 0, (c->nh_l - c->nh_real) * c->hd);
   }
   if (ends_with(name, "mlp.gate_proj.weight")) {
     MI_CHECK(rows == I && cols == c->H, "gate_proj shape");
@@ -457,11 +458,12 @@ int route_vector(mi_ctx* c, const std::string& name, const std::vector<float>& v
   if (qb || kb || vb) {
     MI_CHECK(W.qkv.bias != nullptr, "bias tensor given but the config has qkv_bias = 0");
     const int hd = c->hd;
-    const int src0 = qb ? k.tp_rank * c->q_dim : c->kvh0 * hd;
-    const int cnt = qb ? c->q_dim : c->kv_dim;
+    const int src0 = qb ? c->qh0 * hd : c->kvh0 * hd;
+    const int cnt = qb ? c->nh_real * hd : c->kv_dim;   // padding q heads keep the zero bias of alloc_linear
     const int dst0 = qb ? 0 : (kb ? c->q_dim : c->q_dim + c->kv_dim);
     MI_CHECK(n == (qb ? k.num_heads : k.num_kv_heads) * hd, "qkv bias shape");
     std::vector<float> out(cnt);
+    if (cnt == 0) return MI_OK;
     for (int i = 0; i < cnt; ++i) {
       int j = i;  // destination index of source element i
       if (!vb) {
@@ -537,7 +539,6 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
     return MI_OK;
   }
   MI_CHECK(k.tp_degree >= 1 && (k.tp_rank >= 0 || k.tp_degree == 1) && k.tp_rank < k.tp_degree, "bad tp_degree / tp_rank");
-  MI_CHECK(k.num_heads % k.tp_degree == 0, "num_heads must divide by tp_degree");
   MI_CHECK(k.num_heads % k.num_kv_heads == 0, "num_heads must be a multiple of num_kv_heads");
   MI_CHECK(k.intermediate_size % k.tp_degree == 0 && k.vocab_size % k.tp_degree == 0, "intermediate/vocab must divide by tp_degree");
   MI_CHECK(k.block_size > 0 && k.block_size % 16 == 0, "block_size must be a positive multiple of 16");
@@ -561,10 +562,29 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   const int T = k.tp_degree;
   c->H = k.hidden_size;
   c->hd = k.head_dim;
-  c->nh_l = k.num_heads / T;
-  c->nkv_l = k.num_kv_heads >= T ? k.num_kv_heads / T : 1;
-  MI_CHECK(k.num_kv_heads >= T ? k.num_kv_heads % T == 0 : T % k.num_kv_heads == 0, "num_kv_heads vs tp_degree");
-  c->kvh0 = k.num_kv_heads >= T ? k.tp_rank * c->nkv_l : (k.tp_rank * c->nh_l) / (k.num_heads / k.num_kv_heads);
+  // Head sharding.  kv heads >= ranks: whole kv groups per rank.  Fewer kv heads than ranks: every kv head is
+  // replicated on R = T / nkv ranks and its G q heads are dealt to them ceil(G / R) at a time; where R does not
+  // divide G the last rank(s) of a group hold ZERO-WEIGHT padding heads (q rows, q bias and o_proj columns zero:
+  // they add nothing to the row-parallel sum) -- Qwen2.5-7B at TP 8: 28 q / 4 kv heads -> 4 + 3(+1 pad) per kv
+  // head.  The reference runs such models because it skips vLLM's divisibility check (platform.py:58-64) and
+  // its model library pads heads the same way.
+  MI_CHECK(k.num_kv_heads >= T ? k.num_kv_heads % T == 0 : T % k.num_kv_heads == 0,
+           "num_kv_heads must be a multiple or a divisor of tp_degree");
+  const int G = k.num_heads / k.num_kv_heads;
+  const int tr = c->cfg.tp_rank;
+  if (k.num_kv_heads >= T) {
+    c->nkv_l = k.num_kv_heads / T;
+    c->nh_l = c->nh_real = c->nkv_l * G;
+    c->kvh0 = tr * c->nkv_l;
+    c->qh0 = c->kvh0 * G;
+  } else {
+    const int R = T / k.num_kv_heads, Gl = (G + R - 1) / R, sub = tr % R;
+    c->nkv_l = 1;
+    c->nh_l = Gl;
+    c->kvh0 = tr / R;
+    c->qh0 = std::min(c->kvh0 * G + sub * Gl, (c->kvh0 + 1) * G);
+    c->nh_real = std::max(0, std::min(Gl, G - sub * Gl));
+  }
   MI_CHECK(c->nh_l % c->nkv_l == 0 && c->nh_l / c->nkv_l <= 8, "q heads per kv head (per rank) must be 1..8");
   c->q_dim = c->nh_l * c->hd;
   c->kv_dim = c->nkv_l * c->hd;

@@ -48,7 +48,7 @@ struct mi_ctx {
   hipStream_t stream = nullptr;
   bool finalized = false;
   // per-rank geometry
-  int H = 0, hd = 0, nh_l = 0, nkv_l = 0, kvh0 = 0, q_dim = 0, kv_dim = 0, I_l = 0, V_l = 0, max_rows = 0;
+  int H = 0, hd = 0, nh_l = 0, nh_real = 0, qh0 = 0, nkv_l = 0, kvh0 = 0, q_dim = 0, kv_dim = 0, I_l = 0, V_l = 0, max_rows = 0;
   std::vector<LayerW> layers;
   uint16_t* embed = nullptr;
   Linear lm_head;
