@@ -349,6 +349,7 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
     k.tp_rank = r;
     k.device_id = cfg.tp_device_ids[r];
     if (g->lockstep) k.use_graphs = 0;   // host barriers sit between the exchange kernels
+    if (g->use_rccl) k.use_graphs = 0;   // ncclAllReduce under stream capture on T threads at once: never run anywhere, so not relied on
     mi_ctx* c = nullptr;
     int rc2 = mi_ctx_create(&k, &c);
     if (rc2 != MI_OK) return rc2;
@@ -565,7 +566,10 @@ int group_selftest(mi_group* g) {
     set_error(std::string("peer-memory exchange failed its self-test and ncclCommInitAll failed too: ") + ncclGetErrorString(nr));
     return MI_ECOMM;
   }
-  for (int r = 0; r < g->T; ++r) g->ranks[r]->comm = comms[r];
+  for (int r = 0; r < g->T; ++r) {
+    g->ranks[r]->comm = comms[r];
+    g->ranks[r]->cfg.use_graphs = 0;   // as for an RCCL group from the start (group_create)
+  }
   g->use_rccl = 1;
   g->bar->reset();
   return run();
