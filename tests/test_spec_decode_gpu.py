@@ -1,0 +1,184 @@
+"""Fused speculation (mi_forward_spec) on the MI355X: k chained draft steps + one target pass over
+the B * k candidate rows + greedy acceptance, all on the device.
+
+Reference: NxDI's fused draft + target graph behind
+/root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py:349-355, output contract
+:308-333.  No reference test holds a speculative golden output (parity unpinned); what is checkable
+is (a) the oracle's restatement of the step (oracle/spec_decode.py) on the same inputs and (b) the
+property that greedy acceptance never changes the text: the tokens must be exactly those the target
+alone generates greedily -- for ANY draft (a copy of the target: everything accepted; an unrelated
+model: almost nothing accepted; a perturbed copy: something in between).
+"""
+import dataclasses
+
+import pytest
+import torch
+
+from oracle import PagedDecoderOracle
+from oracle.spec_decode import fused_speculation_step, remask
+from oracle.synth import make_prompts, make_weights, zoo_config
+from tests.helpers import decode_inputs, prefill_inputs
+
+pytestmark = pytest.mark.gpu
+
+BS, MAXLEN, NSEQ, K = 32, 256, 4, 4
+MB = MAXLEN // BS
+NB = 1 + 2 * NSEQ * MB
+
+
+def _model(cfg, weights, max_num_seqs, weight_dtype="bf16"):
+    from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+    rs = cfg.rope_scaling or {}
+    m = NativeModel(
+        num_layers=cfg.num_layers, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads,
+        num_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+        vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+        rope_type=1 if rs else 0, rope_factor=rs.get("factor", 1.0),
+        rope_low_freq_factor=rs.get("low_freq_factor", 1.0), rope_high_freq_factor=rs.get("high_freq_factor", 4.0),
+        rope_original_max_position=rs.get("original_max_position_embeddings", 0),
+        qkv_bias=int(cfg.qkv_bias), tie_word_embeddings=int(cfg.tie_word_embeddings),
+        num_blocks=NB, block_size=BS, max_num_seqs=max_num_seqs, max_model_len=MAXLEN,
+        weight_dtype=MI_W[weight_dtype], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
+        tp_degree=1, tp_rank=0, device_id=0, use_graphs=1, prefill_fp8_activations=0)
+    m.load_state_dict(weights)
+    m.finalize()
+    return m
+
+
+def _drafts(cfg, w):
+    """name -> (draft config, draft weights)"""
+    g = torch.Generator().manual_seed(11)
+    noisy = {}
+    for name, t in w.items():
+        if t.dim() == 2 and "embed" not in name:
+            noisy[name] = (t + torch.randn(t.shape, generator=g) * t.std() * 0.25).to(torch.bfloat16).float()
+        else:
+            noisy[name] = t
+    small = dataclasses.replace(zoo_config("tinyllama_like"), vocab_size=cfg.vocab_size)
+    return {"copy": (cfg, w), "perturbed": (cfg, noisy), "unrelated": (small, make_weights(small, seed=7))}
+
+
+def _plain_greedy(model, prompts, blocks, n_new):
+    out = [[] for _ in prompts]
+    for i, p in enumerate(prompts):
+        out[i].append(int(model.forward(**prefill_inputs(p, blocks[i], BS, MAXLEN, 0)).argmax(dim=1)[0]))
+    for s in range(1, n_new):
+        last = [o[-1] for o in out]
+        pos = [len(p) + s - 1 for p in prompts]
+        ids = model.forward(**decode_inputs(last, pos, blocks, BS, MAXLEN)).argmax(dim=1).tolist()
+        for i, t in enumerate(ids):
+            out[i].append(int(t))
+    return out
+
+
+@pytest.mark.parametrize("weight_dtype", ["bf16", "f8e4m3"])
+@pytest.mark.parametrize("draft_kind", ["copy", "perturbed", "unrelated"])
+def test_fused_speculation_is_lossless_and_matches_the_oracle_step(draft_kind, weight_dtype):
+    cfg = zoo_config("llama31_like")
+    w = make_weights(cfg, seed=1)
+    dcfg, dw = _drafts(cfg, w)[draft_kind]
+    prompts = make_prompts(cfg.vocab_size, 0)
+    n_new = 24
+    target = _model(cfg, w, NSEQ * K, weight_dtype)
+    draft = _model(dcfg, dw, NSEQ, weight_dtype)
+    blocks_a = [[1 + i * MB + j for j in range(MB)] for i in range(NSEQ)]
+    blocks_b = [[1 + (NSEQ + i) * MB + j for j in range(MB)] for i in range(NSEQ)]
+    want = _plain_greedy(target, prompts, blocks_a, n_new)       # the target alone, one token per step
+
+    # speculation on other blocks: prefill both models, first token from the target's prefill
+    got = [[] for _ in prompts]
+    for i, p in enumerate(prompts):
+        inp = prefill_inputs(p, blocks_b[i], BS, MAXLEN, 0)
+        got[i].append(int(target.forward(**inp).argmax(dim=1)[0]))
+        draft.forward(**inp)
+    bt = torch.tensor([b + [0] * (MB - len(b)) for b in blocks_b], dtype=torch.long)
+    steps, produced = 0, 0
+    while min(len(g) for g in got) < n_new:
+        last = torch.tensor([g[-1] for g in got])
+        pos = torch.tensor([len(p) + len(g) - 1 for p, g in zip(prompts, got)])
+        acc, nxt = target.forward_spec(draft, last, pos, bt, K)
+        masked = remask(acc, nxt, pos)
+        for i in range(NSEQ):
+            toks = [int(t) for t in masked[i] if t != -1]
+            assert 1 <= len(toks) <= K and int(nxt[i]) == int(pos[i]) + len(toks)
+            got[i].extend(toks)
+            produced += len(toks)
+        steps += 1
+    for i in range(NSEQ):
+        assert got[i][:n_new] == want[i], (draft_kind, i, got[i][:n_new], want[i])
+    rate = produced / (steps * NSEQ)
+    print(f"{draft_kind}/{weight_dtype}: {rate:.2f} tokens per sequence and step over {steps} steps")
+    if draft_kind == "copy":
+        assert rate == K                                         # the draft IS the target: every candidate accepted
+    if draft_kind == "unrelated":
+        assert rate < 1.5
+    draft.close()
+    target.close()
+
+
+def test_fused_speculation_step_against_the_oracle():
+    """One speculation step at a time, same inputs to the HIP path and to oracle/spec_decode.py
+    (bf16 weights; both sides continue from the ORACLE's accepted tokens, so a near-tie that flips
+    one side's argmax cannot snowball)."""
+    cfg = zoo_config("llama31_like")
+    w = make_weights(cfg, seed=1)
+    dcfg, dw = _drafts(cfg, w)["perturbed"]
+    prompts = make_prompts(cfg.vocab_size, 0)
+    target, draft = _model(cfg, w, NSEQ * K), _model(dcfg, dw, NSEQ)
+    o_target = PagedDecoderOracle(cfg, w, NB, BS, compute="bf16")
+    o_draft = PagedDecoderOracle(dcfg, dw, NB, BS, compute="bf16")
+    blocks = [[1 + i * MB + j for j in range(MB)] for i in range(NSEQ)]
+    seqs = []
+    for i, p in enumerate(prompts):
+        inp = prefill_inputs(p, blocks[i], BS, MAXLEN, 0)
+        first = int(o_target.forward(**inp).argmax(dim=1)[0])
+        o_draft.forward(**inp)
+        target.forward(**inp)
+        draft.forward(**inp)
+        seqs.append([first])
+    bt = torch.tensor(blocks, dtype=torch.long)
+    agree = total = 0
+    for _ in range(8):
+        last = [s[-1] for s in seqs]
+        pos = [len(p) + len(s) - 1 for p, s in zip(prompts, seqs)]
+        acc_o, nxt_o = fused_speculation_step(o_target, o_draft, last, pos, bt, K, BS, MAXLEN)
+        acc, nxt = target.forward_spec(draft, torch.tensor(last), torch.tensor(pos), bt, K)
+        total += NSEQ
+        agree += sum(int(torch.equal(acc[i], acc_o[i]) and nxt[i] == nxt_o[i]) for i in range(NSEQ))
+        m = remask(acc_o, nxt_o, torch.tensor(pos))
+        for i in range(NSEQ):
+            seqs[i].extend(int(t) for t in m[i] if t != -1)
+    print(f"speculation steps identical to the oracle's: {agree}/{total}")
+    assert agree >= total - 2, (agree, total)                    # bf16 near-ties may flip a draft token
+    draft.close()
+    target.close()
+
+
+def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
+    """Candidates beyond max_model_len are never produced; a window that crosses a block boundary
+    takes its slots from the block table (the reference's consecutive slots, runner.py:825-830, hold
+    only inside one block)."""
+    cfg = zoo_config("tinyllama_like")
+    w = make_weights(cfg, seed=3)
+    target, draft = _model(cfg, w, NSEQ * K), _model(cfg, w, NSEQ)
+    g = torch.Generator().manual_seed(5)
+    L = 218                                                       # windows cross the block boundary 223 | 224, then run into position 255
+    p = torch.randint(0, cfg.vocab_size, (L,), generator=g).tolist()
+    blocks = [[9, 3, 12, 5, 1, 14, 7, 2]]                         # scattered blocks
+    inp = prefill_inputs(p, blocks[0], BS, MAXLEN, 0)
+    seq = [int(target.forward(**inp).argmax(dim=1)[0])]
+    draft.forward(**inp)
+    bt = torch.tensor(blocks, dtype=torch.long)
+    while L + len(seq) - 1 < MAXLEN:                              # as long as the last token has a position to be processed at
+        pos = L + len(seq) - 1
+        acc, nxt = target.forward_spec(draft, torch.tensor([seq[-1]]), torch.tensor([pos]), bt, K)
+        n = int(nxt[0]) - pos
+        assert 1 <= n <= min(K, MAXLEN - pos)
+        seq.extend(acc[0, :n].tolist())
+    assert L + len(seq) == MAXLEN + 1                             # the draft is a copy: full windows, the last one clipped
+    # the same text from the target alone (fresh blocks)
+    blocks2 = [[20, 21, 22, 23, 24, 25, 26, 27]]
+    want = _plain_greedy(target, [p], blocks2, len(seq))
+    assert seq == want[0]
+    draft.close()
+    target.close()

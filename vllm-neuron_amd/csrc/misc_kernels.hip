@@ -372,4 +372,62 @@ int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int 
   return MI_OK;
 }
 
+// =====================================================================================
+// fused speculation: the glue between the draft's chained steps and the target's pass
+// =====================================================================================
+__global__ void spec_advance_kernel(int B, int k, int step, const int32_t* __restrict__ draft_tokens,
+                                    int32_t* __restrict__ draft_dec, int draft_rows, const int32_t* __restrict__ draft_bt,
+                                    int MB, int bs, const int32_t* __restrict__ limit, int32_t* __restrict__ target_ids,
+                                    int32_t* __restrict__ cand) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int tok = draft_tokens[b];
+  if (step + 1 < k) {
+    cand[b * k + step + 1] = tok;
+    target_ids[b * k + step + 1] = tok;
+  }
+  int32_t* d_ctx = draft_dec;
+  int32_t* d_ids = draft_dec + draft_rows;
+  int32_t* d_pos = draft_dec + 2 * draft_rows;
+  int32_t* d_slots = draft_dec + 3 * draft_rows;
+  if (step + 1 < limit[b]) {
+    const int pos = d_pos[b] + 1;
+    d_ids[b] = tok;
+    d_pos[b] = pos;
+    d_ctx[b] = pos + 1;
+    d_slots[b] = draft_bt[(size_t)b * MB + pos / bs] * bs + pos % bs;
+  } else {
+    d_slots[b] = -1;   // same row again, nothing written
+  }
+}
+
+int launch_spec_advance(int B, int k, int step, const int32_t* draft_tokens, int32_t* draft_dec, int draft_rows,
+                        const int32_t* draft_bt, int MB, int block_size, const int32_t* limit, int32_t* target_ids,
+                        int32_t* cand, hipStream_t s) {
+  hipLaunchKernelGGL(spec_advance_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, B, k, step, draft_tokens, draft_dec,
+                     draft_rows, draft_bt, MB, block_size, limit, target_ids, cand);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+__global__ void spec_accept_kernel(int B, int k, const int32_t* __restrict__ target_tokens, const int32_t* __restrict__ cand,
+                                   const int32_t* __restrict__ limit, const int32_t* __restrict__ pos0,
+                                   int32_t* __restrict__ out_tokens, int32_t* __restrict__ next_pos) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int lim = limit[b];   // rows of this sequence that were computed: 1..k
+  int n = 0;
+  while (n + 1 < lim && cand[b * k + n + 1] == target_tokens[b * k + n]) ++n;
+  for (int i = 0; i < k; ++i) out_tokens[b * k + i] = i <= n ? target_tokens[b * k + i] : 0;
+  next_pos[b] = pos0[b] + n + 1;
+}
+
+int launch_spec_accept(int B, int k, const int32_t* target_tokens, const int32_t* cand, const int32_t* limit,
+                       const int32_t* pos0, int32_t* out_tokens, int32_t* next_pos, hipStream_t s) {
+  hipLaunchKernelGGL(spec_accept_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, B, k, target_tokens, cand, limit, pos0,
+                     out_tokens, next_pos);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 }  // namespace mi

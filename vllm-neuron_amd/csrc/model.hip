@@ -630,9 +630,9 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_inputs, c->d_dec, c->d_dec_bt, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws};
+                  c->attn_scratch, c->d_inputs, c->d_dec, c->d_dec_bt, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws, c->d_spec};
   for (void* p : ptrs) hipFree(p);
-  void* hptrs[] = {c->h_inputs, c->h_dec, c->h_dec_bt, c->h_sparams, c->h_tokens, c->h_logits};
+  void* hptrs[] = {c->h_inputs, c->h_dec, c->h_dec_bt, c->h_sparams, c->h_tokens, c->h_logits, c->h_spec};
   for (void* p : hptrs) if (p) hipHostFree(p);
   if (c->stream_owned) hipStreamDestroy(c->stream);
   delete c;
@@ -1012,6 +1012,59 @@ static void set_input_views(mi_ctx* c, bool decode_step) {
   }
 }
 
+// ---- staging of a token-generation batch: 4 ints per row + the block-table rows that changed ----
+// (block tables are resident on the device; a row is re-sent only when it differs from the host
+//  shadow of what the device holds, and only entries that became live are range-checked)
+struct DecodeStage { int row_lo = 0, row_hi = -1; };
+static void decode_stage_begin(mi_ctx* c, int MB, int B, DecodeStage& st) {
+  const mi_model_config& k = c->cfg;
+  if (c->bt_shadow_MB != MB) {   // another table width: nothing on the device can be reused
+    c->bt_shadow.assign((size_t)k.max_num_seqs * MB, INT64_MIN);
+    c->bt_shadow_MB = MB;
+    std::fill(c->bt_checked.begin(), c->bt_checked.end(), 0);
+  }
+  st.row_lo = B;   // rows whose device copy is stale: [row_lo, row_hi]
+  st.row_hi = -1;
+}
+static int decode_stage_row(mi_ctx* c, int b, int MB, int64_t id, int64_t pos, int64_t slot, int full, const int64_t* row,
+                            DecodeStage& st) {
+  const mi_model_config& k = c->cfg;
+  const int bs = k.block_size;
+  MI_CHECK(full >= 1 && full <= k.max_model_len, "full_context_lens out of range");
+  const int need = ceil_div(full, bs);
+  MI_CHECK(need <= MB, "block_table narrower than the context");
+  int64_t* shadow = c->bt_shadow.data() + (size_t)b * MB;
+  if (memcmp(row, shadow, (size_t)MB * 8) != 0) {   // new request in this row / block appended: re-send the row
+    memcpy(shadow, row, (size_t)MB * 8);
+    for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)row[j];
+    c->bt_checked[b] = 0;
+    st.row_lo = std::min(st.row_lo, b);
+    st.row_hi = std::max(st.row_hi, b);
+    c->bt_rows_sent += 1;
+  } else {
+    c->bt_rows_kept += 1;
+  }
+  for (int j = c->bt_checked[b]; j < need; ++j)   // only the entries that became live
+    MI_CHECK(row[j] >= 0 && row[j] < k.num_blocks, "block_table entry out of range inside the live context");
+  c->bt_checked[b] = std::max(c->bt_checked[b], need);
+  MI_CHECK(pos >= 0 && pos < k.max_model_len, "position out of range");
+  MI_CHECK(id >= 0 && id < k.vocab_size, "token id out of range");
+  MI_CHECK(slot >= -1 && slot < (int64_t)k.num_blocks * bs, "slot out of range");
+  c->h_ids[b] = (int32_t)id;
+  c->h_pos[b] = (int32_t)pos;
+  c->h_slots[b] = (int32_t)slot;
+  c->h_ctx[b] = full;
+  return MI_OK;
+}
+static int decode_stage_push(mi_ctx* c, int MB, const DecodeStage& st) {   // 4 x max_num_seqs ints, + the table rows that changed
+  hipStream_t s = c->stream;
+  MI_HIP(hipMemcpyAsync(c->d_dec, c->h_dec, (size_t)c->cfg.max_num_seqs * 16, hipMemcpyHostToDevice, s));
+  if (st.row_hi >= st.row_lo)
+    MI_HIP(hipMemcpyAsync(c->d_dec_bt + (size_t)st.row_lo * MB, c->h_dec_bt + (size_t)st.row_lo * MB,
+                          (size_t)(st.row_hi - st.row_lo + 1) * MB * 4, hipMemcpyHostToDevice, s));
+  return MI_OK;
+}
+
 // logits_out != null: the reference's CPU-sampling contract (fp32 logits of the last token of every
 // row to the host).  tokens_out != null: on-device sampling -- the ids are sampled from the device
 // logits and only B integers cross PCIe.
@@ -1091,48 +1144,12 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
   if (S == 1) {  // ---- token generation -------------------------------------------------
     g_ht.start();
     use_inputs(true);
-    if (c->bt_shadow_MB != MB) {   // another table width: nothing on the device can be reused
-      c->bt_shadow.assign((size_t)k.max_num_seqs * MB, INT64_MIN);
-      c->bt_shadow_MB = MB;
-      std::fill(c->bt_checked.begin(), c->bt_checked.end(), 0);
-    }
-    int row_lo = B, row_hi = -1;   // rows whose device copy is stale
-    for (int b = 0; b < B; ++b) {
-      const int full = (int)full_context_lens[b];
-      MI_CHECK(full >= 1 && full <= k.max_model_len, "full_context_lens out of range");
-      const int need = ceil_div(full, bs);
-      MI_CHECK(need <= MB, "block_table narrower than the context");
-      const int64_t* row = block_table + (size_t)b * MB;
-      int64_t* shadow = c->bt_shadow.data() + (size_t)b * MB;
-      if (memcmp(row, shadow, (size_t)MB * 8) != 0) {   // new request in this row / block appended: re-send the row
-        memcpy(shadow, row, (size_t)MB * 8);
-        for (int j = 0; j < MB; ++j) c->h_bt[(size_t)b * MB + j] = (int32_t)row[j];
-        c->bt_checked[b] = 0;
-        row_lo = std::min(row_lo, b);
-        row_hi = std::max(row_hi, b);
-        c->bt_rows_sent += 1;
-      } else {
-        c->bt_rows_kept += 1;
-      }
-      for (int j = c->bt_checked[b]; j < need; ++j)   // only the entries that became live
-        MI_CHECK(row[j] >= 0 && row[j] < k.num_blocks, "block_table entry out of range inside the live context");
-      c->bt_checked[b] = std::max(c->bt_checked[b], need);
-      const int64_t pos = position_ids[b], slot = slot_mapping[(size_t)b * SM];
-      MI_CHECK(pos >= 0 && pos < k.max_model_len, "position out of range");
-      MI_CHECK(input_ids[b] >= 0 && input_ids[b] < V, "token id out of range");
-      MI_CHECK(slot >= -1 && slot < (int64_t)k.num_blocks * bs, "slot out of range");
-      c->h_ids[b] = (int32_t)input_ids[b];
-      c->h_pos[b] = (int32_t)pos;
-      c->h_slots[b] = (int32_t)slot;
-      c->h_ctx[b] = full;
-    }
-    auto push_inputs = [&]() -> int {   // 4 x max_num_seqs ints, + the table rows that changed
-      MI_HIP(hipMemcpyAsync(c->d_dec, c->h_dec, (size_t)k.max_num_seqs * 16, hipMemcpyHostToDevice, s));
-      if (row_hi >= row_lo)
-        MI_HIP(hipMemcpyAsync(c->d_dec_bt + (size_t)row_lo * MB, c->h_dec_bt + (size_t)row_lo * MB,
-                              (size_t)(row_hi - row_lo + 1) * MB * 4, hipMemcpyHostToDevice, s));
-      return MI_OK;
-    };
+    DecodeStage st;
+    decode_stage_begin(c, MB, B, st);
+    for (int b = 0; b < B; ++b)
+      MI_TRY(decode_stage_row(c, b, MB, input_ids[b], position_ids[b], slot_mapping[(size_t)b * SM], (int)full_context_lens[b],
+                              block_table + (size_t)b * MB, st));
+    auto push_inputs = [&]() -> int { return decode_stage_push(c, MB, st); };
     g_ht.lap(0);
     MI_TRY(push_inputs());
     g_ht.lap(1);
@@ -1250,6 +1267,94 @@ int mi_forward_chunked(mi_ctx* c, int32_t n_req, int32_t total, const int64_t* i
   if (tokens_out) MI_TRY(sample_on_device(c, n_req, 0, sampling_params, seed, tokens_out));
   else MI_TRY(fetch_logits(c, n_req, logits_out));
   return prof_collect(c);
+}
+
+// Fused speculation: k chained token-generation steps of the DRAFT context (its greedy token feeds its
+// next step on the device), ONE token-generation pass of the TARGET over the B * k candidate rows
+// (row b * k + i = candidate i of sequence b at position pos_b + i: the M <= 16 weight-streaming
+// kernels read every weight once for all of them), greedy acceptance on the device.  Reference: NxDI's
+// fused speculation behind /root/reference/vllm_neuron/worker/neuronx_distributed_model_loader.py:349-355
+// (output contract: accepted tokens 0-padded to the speculation length + next position ids, re-masked
+// by _remask_fused_spec_output :308-333) and the runner's slots for the speculated positions
+// (neuronx_distributed_model_runner.py:825-830; here taken from the block table, so a window may
+// cross a block boundary).  The draft runs all k steps so that its K/V covers every token the
+// target can accept; K/V written for rejected candidates is overwritten by the next call.
+int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* input_ids, const int64_t* position_ids,
+                    const int64_t* block_table, int32_t MB, int64_t* accepted_out, int64_t* next_pos_out) {
+  MI_CHECK(t && d && t != d && t->finalized && d->finalized, "mi_forward_spec: two finalized contexts (target, draft)");
+  MI_CHECK(!t->owned_group && !d->owned_group && !t->grp && !d->grp && !t->collective() && !d->collective(),
+           "mi_forward_spec: tensor-parallel contexts are not supported");
+  MI_CHECK(input_ids && position_ids && block_table && accepted_out && next_pos_out, "null argument");
+  const mi_model_config& kt = t->cfg;
+  const mi_model_config& kd = d->cfg;
+  MI_CHECK(kt.device_id == kd.device_id && kt.block_size == kd.block_size && kt.num_blocks == kd.num_blocks &&
+           kt.vocab_size == kd.vocab_size && kt.max_model_len == kd.max_model_len,
+           "mi_forward_spec: target and draft must share device, block_size, num_blocks, vocab_size and max_model_len");
+  MI_CHECK(B >= 1 && k >= 1 && B * k <= kt.max_num_seqs && B <= kd.max_num_seqs,
+           "mi_forward_spec: B * k rows exceed the target's max_num_seqs (or B the draft's)");
+  MI_CHECK(MB >= 1 && MB <= t->MB_cap && MB <= d->MB_cap, "bad block-table width");
+  MI_HIP(hipSetDevice(kt.device_id));
+  if (d->stream != t->stream) {   // one stream for both contexts: the chain below is ordered by enqueue order alone
+    MI_HIP(hipStreamSynchronize(d->stream));
+    if (d->stream_owned) hipStreamDestroy(d->stream);
+    d->stream = t->stream;
+    d->stream_owned = false;
+  }
+  hipStream_t s = t->stream;
+  const size_t ms = (size_t)kt.max_num_seqs;
+  if (!t->d_spec) {   // [cand][limit][pos0][out][next_pos], max_num_seqs ints each
+    MI_HIP(hipMalloc(&t->d_spec, 5 * ms * 4));
+    MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t->h_spec), 5 * ms * 4, hipHostMallocDefault));
+    memset(t->h_spec, 0, 5 * ms * 4);
+  }
+  int32_t *d_cand = t->d_spec, *d_limit = t->d_spec + ms, *d_pos0 = t->d_spec + 2 * ms, *d_out = t->d_spec + 3 * ms;
+  int32_t *h_limit = t->h_spec + ms, *h_pos0 = t->h_spec + 2 * ms, *h_out = t->h_spec + 3 * ms;
+  const int bs = kt.block_size;
+
+  set_input_views(t, true);
+  set_input_views(d, true);
+  DecodeStage st_t, st_d;
+  decode_stage_begin(t, MB, B * k, st_t);
+  decode_stage_begin(d, MB, B, st_d);
+  for (int b = 0; b < B; ++b) {
+    const int64_t pos = position_ids[b];
+    MI_CHECK(pos >= 0 && pos < kt.max_model_len, "position out of range");
+    const int lim = (int)std::min<int64_t>(k, kt.max_model_len - pos);   // candidate rows that fit the model length
+    const int64_t* row = block_table + (size_t)b * MB;
+    MI_CHECK(ceil_div((int)pos + lim, bs) <= MB, "block_table narrower than the speculation window");
+    auto slot_of = [&](int64_t p) { return row[p / bs] * bs + p % bs; };
+    for (int i = 0; i < k; ++i) {
+      const int64_t p = pos + std::min(i, lim - 1);
+      MI_TRY(decode_stage_row(t, b * k + i, MB, i == 0 ? input_ids[b] : 0, p, i < lim ? slot_of(p) : -1, (int)p + 1, row, st_t));
+    }
+    MI_TRY(decode_stage_row(d, b, MB, input_ids[b], pos, slot_of(pos), (int)pos + 1, row, st_d));
+    // the whole window must be backed by real blocks (decode_stage_row checked the live context of its last row)
+    h_limit[b] = lim;
+    h_pos0[b] = (int32_t)pos;
+  }
+  MI_TRY(decode_stage_push(t, MB, st_t));
+  MI_TRY(decode_stage_push(d, MB, st_d));
+  MI_HIP(hipMemcpyAsync(d_limit, h_limit, 2 * ms * 4, hipMemcpyHostToDevice, s));   // limit + pos0 (adjacent)
+  for (int step = 0; step < k; ++step) {
+    MI_TRY(capture_or_launch_decode(d, B, MB));
+    if (step + 1 < k) {
+      MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s));
+      MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
+                                 d_cand, s));
+    }
+  }
+  MI_TRY(capture_or_launch_decode(t, B * k, MB));
+  MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s));
+  MI_TRY(launch_spec_accept(B, k, t->d_tokens, d_cand, d_limit, d_pos0, d_out, d_out + ms, s));
+  MI_HIP(hipMemcpyAsync(h_out, d_out, 2 * ms * 4, hipMemcpyDeviceToHost, s));   // out + next_pos (adjacent)
+  MI_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < B * k; ++i) accepted_out[i] = h_out[i];
+  for (int b = 0; b < B; ++b) next_pos_out[b] = h_out[ms + b];
+  t->last_B = B * k;
+  t->last_MB = MB;
+  d->last_B = B;
+  d->last_MB = MB;
+  return MI_OK;
 }
 
 int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {
