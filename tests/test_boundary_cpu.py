@@ -563,3 +563,105 @@ def test_unsupported_features_raise():
     rr = MI355XModelRunner(c, "cpu")
     with pytest.raises(NotImplementedError, match="Multi-lora"):
         rr.load_model()
+
+
+# ---- fused speculation (reference loader.py:243-334, 785-791; runner.py:293-345, 488-498, 825-830) -------------
+def test_remask_fused_spec_output_known_answer():               # reference test_model_loader.py:1175-1210
+    fused = [torch.tensor([[1, 2, 0], [3, 0, 0]]),               # accepted tokens, 0-padded (0 is ALSO a real token id)
+             torch.tensor([[5], [4]])]                           # next position ids
+    inputs = {"position_ids": torch.tensor([[2], [3]])}
+    masked = loader.MI355XCausalLM._remask_fused_spec_output(None, fused, inputs)
+    assert masked.tolist() == [[1, 2, 0], [3, -1, -1]]           # row 0 generated 3 tokens (the 0 is one), row 1 one
+    # counts are clamped to [0, T]; a 1-D next-position vector is accepted too
+    fused = [torch.tensor([[7, 8], [9, 9], [4, 0]]), torch.tensor([9, 3, 6])]
+    inputs = {"position_ids": torch.tensor([[0, 1, 2], [1, 2, 3], [3, 4, 5]])}
+    assert loader.MI355XCausalLM._remask_fused_spec_output(None, fused, inputs).tolist() == [[7, 8], [-1, -1], [4, -1]]
+
+
+def test_speculative_defaults_and_eagle_is_rejected():           # reference loader.py:785-791
+    from vllm_neuron_amd._vllm_compat import SimpleSpeculativeConfig
+    c = vcfg()
+    spec = SimpleSpeculativeConfig(num_speculative_tokens=4)
+    d = loader._get_default_mi355x_config(c.model_config, c.cache_config, c.parallel_config, c.scheduler_config, None, spec)
+    assert d["enable_fused_speculation"] is True and d["speculation_length"] == 4 and "enable_eagle_speculation" not in d
+    d = loader._get_default_mi355x_config(c.model_config, c.cache_config, c.parallel_config, c.scheduler_config, None,
+                                          SimpleSpeculativeConfig(num_speculative_tokens=2, method="eagle"))
+    assert d["enable_eagle_speculation"] is True
+    d = loader._get_default_mi355x_config(c.model_config, c.cache_config, c.parallel_config, c.scheduler_config, None, None)
+    assert "enable_fused_speculation" not in d
+    with pytest.raises(NotImplementedError, match="EAGLE"):
+        loader.get_mi355x_model(c.model_config, c.cache_config, c.parallel_config, c.scheduler_config, None,
+                                speculative_config=SimpleSpeculativeConfig(method="eagle"))
+
+
+def test_runner_output_with_speculative_config():                # reference test_model_runner.py:720-770
+    from vllm_neuron_amd._vllm_compat import SimpleSpeculativeConfig
+    r = make_runner()
+    r.speculative_config = SimpleSpeculativeConfig(num_speculative_tokens=3)
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [1])]))
+    r.execute_model(sched_out([new_req("b", [1, 2], [2])]))
+    cached = CachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[False, False], new_token_ids=[[], []],
+                               new_block_ids=[None, None], num_computed_tokens=[3, 2])
+    r.execute_model(sched_out(cached=cached))
+    ids = r.input_batch.req_ids
+    before = {rid: list(r.requests[rid].output_token_ids) for rid in ids}
+    # [B, T, 1] as the fused step returns it: row 0 generated 3 tokens (one of them id 0), row 1 one token
+    out = r._generate_model_runner_output(SamplerOutput(sampled_token_ids=torch.tensor([[[5], [0], [7]], [[9], [-1], [-1]]])))
+    assert out.sampled_token_ids == [[5, 0, 7], [9]]
+    assert r.spec_token_ids == [[5, 0], []]                      # all but the last generated token of each row
+    assert r.requests[ids[0]].output_token_ids == before[ids[0]] + [5, 0, 7]
+    assert r.requests[ids[1]].output_token_ids == before[ids[1]] + [9]
+    row = r.input_batch.req_id_to_index[ids[0]]
+    n = r.input_batch.num_tokens_no_spec[row]
+    assert r.input_batch.token_ids_cpu[row, n - 3:n].tolist() == [5, 0, 7] and r.input_batch.num_tokens[row] == n
+    # the next token-generation step feeds the LAST token at the position behind everything generated
+    r.execute_model(sched_out(cached=cached))
+    kw = r.model.calls[-1]
+    a = cached.req_ids.index(ids[0])                             # rows of the call follow the scheduler's order
+    pos = len(r.requests[ids[0]].prompt_token_ids) + len(before[ids[0]]) + 3 - 1
+    assert kw["position_ids"][a].tolist() == [pos] and kw["input_ids"][a].tolist() == [7]
+    # slots of the speculation window: looked up per position; beyond the owned blocks: the pad
+    bs = r.cache_config.block_size
+    blk = r.requests[ids[0]].block_ids[0]
+    assert kw["slot_mapping"].shape[1] == 3
+    assert kw["slot_mapping"][a].tolist() == [blk[p // bs] * bs + p % bs if p // bs < len(blk) else -1
+                                              for p in range(pos, pos + 3)]
+
+
+def test_update_states_with_scheduled_spec_tokens():             # reference test_model_runner.py:1163-1215
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3, 4, 5], [1])]))
+    cached = CachedRequestData(req_ids=["a"], resumed_from_preemption=[False], new_token_ids=[[]],
+                               new_block_ids=[None], num_computed_tokens=[5])
+    so = sched_out(cached=cached)
+    so.scheduled_spec_decode_tokens = {"a": [10, 11, 12]}
+    row = r.input_batch.req_id_to_index["a"]
+    n = r.input_batch.num_tokens_no_spec[row]
+    r._update_states(so)
+    assert r.input_batch.token_ids_cpu[row, n:n + 3].tolist() == [10, 11, 12]
+    assert r.input_batch.num_tokens[row] == n + 3 and r.input_batch.num_tokens_no_spec[row] == n
+
+
+def test_scheduler_reserves_blocks_for_the_speculation_window():
+    """vLLM's num_lookahead_tokens: a running request owns blocks for the positions a speculation
+    step may write; several tokens per step are appended and the stop rule trims them."""
+    from vllm_neuron_amd._vllm_compat import KVCacheConfig, Request, SimpleSpeculativeConfig
+    from vllm_neuron_amd.core.scheduler import ContinuousBatchingMI355XScheduler
+    c = vcfg(block_size=32, max_model_len=256)
+    c.speculative_config = SimpleSpeculativeConfig(num_speculative_tokens=4)
+    plat.MI355XPlatform.check_and_update_config(c)
+    s = ContinuousBatchingMI355XScheduler(c, KVCacheConfig(num_blocks=33))
+    s.add_request(Request("a", list(range(30)), SamplingParams(temperature=0.0, max_tokens=6), eos_token_id=None))
+    out = s.schedule()
+    assert len(out.scheduled_new_reqs[0].block_ids[0]) == 1                       # 30 prompt tokens: one block
+    mro = SimpleNamespace(req_id_to_index={"a": 0}, sampled_token_ids=[[100]])
+    s.update_from_output(out, mro)
+    out = s.schedule()                                                             # 31 tokens + 4 ahead -> a second block
+    assert out.scheduled_cached_reqs.new_block_ids[0] is not None and len(s.requests["a"].block_ids) == 2
+    mro = SimpleNamespace(req_id_to_index={"a": 0}, sampled_token_ids=[[101, 102, 103, 104]])
+    res = s.update_from_output(out, mro)
+    assert res[0].new_token_ids == [101, 102, 103, 104] and not res[0].finished
+    out = s.schedule()
+    mro = SimpleNamespace(req_id_to_index={"a": 0}, sampled_token_ids=[[105, 106, 107]])
+    res = s.update_from_output(out, mro)                                            # max_tokens 6: the window is trimmed
+    assert res[0].new_token_ids == [105] and res[0].finished

@@ -182,3 +182,66 @@ def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
     assert seq == want[0]
     draft.close()
     target.close()
+
+
+# ---- the whole plugin path: MI355XEngine(speculative_config=...) ---------------------------------
+def _hf_like(cfg, model_type="llama"):
+    from types import SimpleNamespace
+    return SimpleNamespace(
+        architectures=["LlamaForCausalLM"], model_type=model_type, vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+        intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
+        num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads, head_dim=cfg.head_dim,
+        rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, rope_scaling=cfg.rope_scaling,
+        tie_word_embeddings=False)
+
+
+@pytest.mark.parametrize("draft_kind,quant", [("perturbed", False), ("copy", True), ("unrelated", False)])
+def test_engine_with_speculative_config_generates_the_target_text(draft_kind, quant):
+    """vLLM's speculative_config through the plugin (reference loader.py:785-791, 349-355;
+    runner.py:293-345): same prompts, same greedy text as the engine without a draft model; the HF
+    goldens hold for it as for every other greedy path; steps produce several tokens."""
+    from tests.test_engine_gpu import check_against_golden
+    from vllm_neuron_amd._vllm_compat import SamplingParams, SimpleModelConfig, SimpleSpeculativeConfig
+    from vllm_neuron_amd.engine import MI355XEngine
+    name = "llama31_like"
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=1)
+    dcfg, dw = _drafts(cfg, w)[draft_kind]
+    prompts = make_prompts(cfg.vocab_size, 0)
+    sp = SamplingParams(temperature=0.0, max_tokens=12)
+    q = {"quantized": True, "quantization_dtype": "f8e4m3", "quantization_type": "per_channel_symmetric"} if quant else {}
+
+    plain = MI355XEngine(_hf_like(cfg), max_model_len=256, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                         override_mi355x_config={"state_dict": w, **q})
+    want = [o.token_ids for o in plain.generate(prompts, sp)]
+    plain.worker.model_runner.model.model.close()
+
+    spec = SimpleSpeculativeConfig(num_speculative_tokens=K, draft_model_config=SimpleModelConfig(model="", hf_config=_hf_like(dcfg)))
+    eng = MI355XEngine(_hf_like(cfg), max_model_len=256, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                       speculative_config=spec, override_mi355x_config={"state_dict": w, "draft_state_dict": dw, **q})
+    mcfg = eng.worker.model_runner.model.mi355x_config
+    assert mcfg.enable_fused_speculation and mcfg.speculation_length == K and mcfg.on_device_sampling_config
+    steps = 0
+    for p in prompts:
+        eng.add_request(p, sp)
+    multi = 0
+    while eng.has_unfinished_requests():
+        _, out = eng.step()
+        steps += 1
+        multi += sum(len(t) > 1 for t in out.sampled_token_ids)
+    outs = [eng.outputs[f"req-{i}"] for i in range(len(prompts))]
+    got = [o.token_ids for o in outs]
+    assert got == want, (draft_kind, got, want)
+    assert all(o.finished and len(o.token_ids) == 12 for o in outs)
+    if not quant:
+        check_against_golden(name, outs)
+    if draft_kind != "unrelated":
+        assert multi > 0                     # some step generated more than one token for a request
+    # sampling requests are refused: acceptance is by greedy agreement
+    eng.add_request(prompts[0], SamplingParams(temperature=0.8, top_k=20, max_tokens=4))
+    with pytest.raises(Exception, match="greedy"):
+        while eng.has_unfinished_requests():
+            eng.step()
+    runner = eng.worker.model_runner
+    runner.model.draft.close()
+    runner.model.model.close()

@@ -500,6 +500,10 @@ else:
             self.max_model_len = self.scheduler_config.max_model_len
             self.block_size = self.cache_config.block_size
             self.chunked_prefill = bool(getattr(self.scheduler_config, "chunked_prefill_enabled", False))
+            # speculative decoding: KV blocks are reserved that many positions ahead of a running request
+            # (vLLM's num_lookahead_tokens); a step may then produce up to that many tokens per request
+            spec = getattr(vllm_config, "speculative_config", None)
+            self.num_lookahead_tokens = int(getattr(spec, "num_speculative_tokens", 0) or 0) if spec is not None else 0
             num_blocks = kv_cache_config.num_blocks if kv_cache_config else self.cache_config.num_gpu_blocks
             self.block_pool = _BlockPool(num_blocks, self.block_size,
                                          bool(self.cache_config.enable_prefix_caching))
@@ -530,7 +534,8 @@ else:
                 n_tok = req.num_tokens - req.num_computed_tokens
                 if self.chunked_prefill:
                     n_tok = min(n_tok, budget)           # the next chunk of a long prompt
-                need = self._blocks_needed(req, req.num_computed_tokens + n_tok)
+                after = min(req.num_computed_tokens + n_tok + self.num_lookahead_tokens, self.max_model_len)
+                need = self._blocks_needed(req, max(after, req.num_computed_tokens + n_tok))
                 new_blocks = self.block_pool.allocate(need) if need > 0 else []
                 if new_blocks is None:
                     break                      # out of KV blocks: leave the rest unscheduled
@@ -659,6 +664,15 @@ class SimpleSchedulerConfig:
     max_model_len: int = 2048
     chunked_prefill_enabled: bool = False
     scheduler_cls: Any = None
+
+
+@dataclass
+class SimpleSpeculativeConfig:
+    """The attributes of vllm.config.SpeculativeConfig the plugin reads (reference loader.py:785-791,
+    292-301; runner.py:828-830)."""
+    num_speculative_tokens: int = 4
+    method: Optional[str] = None            # "eagle" selects EAGLE drafts in the reference
+    draft_model_config: Any = None          # a ModelConfig: .model (path), .hf_config
 
 
 @dataclass

@@ -37,7 +37,7 @@ class MI355XEngine:
     def __init__(self, hf_config, model: str = "", *, max_model_len=2048, max_num_seqs=4, block_size=32,
                  num_gpu_blocks_override=None, enable_prefix_caching=True, tensor_parallel_size=1,
                  dtype="bfloat16", override_mi355x_config: dict | None = None, seed=0, local_rank=0,
-                 enable_chunked_prefill=False, max_num_batched_tokens=None):
+                 enable_chunked_prefill=False, max_num_batched_tokens=None, speculative_config=None):
         if HAVE_VLLM:  # pragma: no cover
             raise RuntimeError("vLLM is installed: use vllm.LLM(...) — the plugin registers itself")
         cfg = SimpleVllmConfig(
@@ -49,7 +49,7 @@ class MI355XEngine:
             scheduler_config=SimpleSchedulerConfig(max_num_seqs=max_num_seqs, max_model_len=max_model_len,
                                                    chunked_prefill_enabled=bool(enable_chunked_prefill),
                                                    max_num_batched_tokens=int(max_num_batched_tokens or 131072)),
-            device_config=SimpleDeviceConfig("cpu"),
+            device_config=SimpleDeviceConfig("cpu"), speculative_config=speculative_config,
             additional_config={"override_mi355x_config": dict(override_mi355x_config or {})})
         if enable_chunked_prefill:
             # vLLM's native scheduler (the plugin's override is off: DISABLE_MI355X_CUSTOM_SCHEDULER=1,

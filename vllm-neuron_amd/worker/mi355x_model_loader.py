@@ -114,6 +114,48 @@ class MI355XModelBase(nn.Module):
 class MI355XCausalLM(MI355XModelBase):
     """`forward` = one call of libmi355x_vllm's mi_forward (reference loader.py:336-365)."""
 
+    draft = None     # NativeModel of the draft model when fused speculation is on
+
+    def _remask_fused_spec_output(self, fused, inputs):
+        """The fused speculation step hands back (reference loader.py:308-333)
+            fused[0]  = the accepted tokens, [B, T], padded with 0
+            fused[-1] = the position ids the sequences continue from.
+        Token id 0 is a real token, so the padding is turned into -1 here -- everything behind the
+        number of tokens generated in this step, next position minus the position of the token
+        that was fed in -- and the runner strips the -1 entries."""
+        accepted = fused[0]
+        next_pos = fused[-1]
+        next_pos = next_pos.squeeze(-1) if next_pos.dim() > 1 else next_pos
+        fed = inputs["position_ids"][:, -1].to(next_pos.device)
+        width = accepted.shape[1]
+        counts = (next_pos - fed).to(torch.long).clamp_(0, width)
+        columns = torch.arange(width, device=accepted.device)[None, :]
+        return torch.where(columns < counts[:, None], accepted, torch.full_like(accepted, -1))
+
+    def _forward_fused_speculation(self, ids, seq_ids, inputs, block_table, slot_mapping, computed):
+        """Fused speculation (reference loader.py:349-355: the model call returns accepted tokens in
+        place of logits).  Context encoding runs the target (its greedy token is the one generated)
+        and the draft (to fill its K/V); token generation is ONE mi_forward_spec call."""
+        cfg = self.mi355x_config
+        k = int(cfg.speculation_length)
+        sp = inputs.get("sampling_params")
+        if sp is not None and bool((sp[:, 0] != 1).any()):
+            raise NotImplementedError("fused speculation accepts by greedy agreement: every request must sample "
+                                      "greedily (temperature 0 / top_k 1)")
+        positions = inputs["position_ids"]
+        B = ids.shape[0]
+        if ids.shape[1] > 1:      # context encoding
+            first = self.model.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping,
+                                              inputs["full_context_lens"], computed, sampling_params=None, seed=0)
+            self.draft.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping,
+                                      inputs["full_context_lens"], computed, sampling_params=None, seed=0)
+            accepted = torch.zeros(B, k, dtype=torch.long)
+            accepted[:, 0] = first.reshape(B)
+            next_pos = inputs["full_context_lens"].reshape(B).to(torch.long)
+        else:
+            accepted, next_pos = self.model.forward_spec(self.draft, ids[:, 0], positions[:, 0], block_table, k)
+        return self._remask_fused_spec_output([accepted, next_pos.reshape(B, 1)], inputs)
+
     def forward(self, input_ids, input_block_ids, **kwargs):
         cfg = self.mi355x_config
         if cfg.get("chunked_prefill_config") is not None:
@@ -132,6 +174,8 @@ class MI355XCausalLM(MI355XModelBase):
                 # contiguous KV: prefill computes everything, decode everything but the new token
                 full = inputs["full_context_lens"].reshape(-1)
                 computed = torch.zeros_like(full) if ids.shape[1] > 1 else full - 1
+            if cfg.get("enable_fused_speculation"):
+                return restore(self._forward_fused_speculation(ids, seq_ids, inputs, block_table, slot_mapping, computed))
             if cfg.on_device_sampling_config:
                 # the model returns sampled ids in place of logits (reference loader.py:350-356);
                 # sampling_params rows = (top_k, top_p, temperature), greedy rewritten to top_k = 1
@@ -216,9 +260,17 @@ class MI355XCausalLM(MI355XModelBase):
             # the ragged batch here holds up to chunked_prefill_config.max_num_seqs requests
             max_num_seqs = int(getattr(chunked, "max_num_seqs", None) or cfg.get("scheduler_max_num_seqs") or max_num_seqs)
             buckets = sorted(set(buckets + [int(cfg["max_context_length"])]))
+        speculative_config = kwargs.get("speculative_config")
+        fused_spec = bool(cfg.get("enable_fused_speculation"))
+        spec_len = int(cfg.get("speculation_length") or 0) if fused_spec else 0
+        if fused_spec:
+            if spec_len < 1 or speculative_config is None or chunked or tp_degree > 1 or not cfg["is_block_kv_layout"]:
+                raise NotImplementedError("fused speculation needs num_speculative_tokens >= 1, a draft model, the block "
+                                          "KV layout (prefix caching on), tensor_parallel_size 1 and no chunked prefill")
         self.model = NativeModel(
             num_blocks=int(num_blocks), block_size=int(block_size),
-            max_num_seqs=max_num_seqs, max_model_len=int(max_model_len),
+            # the target scores every sequence's speculation window in one token-generation pass
+            max_num_seqs=max_num_seqs * max(spec_len, 1), max_model_len=int(max_model_len),
             ctx_buckets=buckets,
             weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0,
             quant_type=_QUANT_TYPES[qtype] if quantized else 0,
@@ -232,6 +284,9 @@ class MI355XCausalLM(MI355XModelBase):
             use_graphs=int(cfg.get("use_graphs", 1)),
             prefill_fp8_activations=int(bool(cfg.get("prefill_fp8_activations", False))),
             **geo)
+        if fused_spec:
+            self._load_draft(speculative_config, cfg, num_blocks, block_size, max_num_seqs, max_model_len, buckets,
+                             quantized, qdtype, qtype, not_converted, kwargs)
         synthetic = cfg.get("synthetic_weights")
         state_dict = cfg.get("state_dict")
         # Device-ready weight images on disk (quantized, tiled, sharded), the counterpart of the
@@ -258,6 +313,38 @@ class MI355XCausalLM(MI355XModelBase):
             self.model.save_artifacts(artifacts)
             logger.info("Saved weight artifacts to %s", artifacts)
         return False, artifacts
+
+    def _load_draft(self, speculative_config, cfg, num_blocks, block_size, max_num_seqs, max_model_len, buckets,
+                    quantized, qdtype, qtype, not_converted, kwargs) -> None:
+        """The draft model of fused speculation (reference loader.py:243-303: a clone of the target's
+        configuration around the draft checkpoint, fused speculation switched off in the clone).  Same
+        block ids as the target, a K/V pool of its own; quantized like the target unless
+        draft_model_modules_to_not_convert says otherwise."""
+        from .._native import NativeModel
+        draft_cfg = speculative_config.draft_model_config
+        geo = _decoder_geometry(draft_cfg.hf_config)
+        if geo["vocab_size"] != self.hf_config.vocab_size:
+            raise ValueError("fused speculation: draft and target must share the vocabulary")
+        draft_skip = cfg.get("draft_model_modules_to_not_convert") or not_converted
+        self.draft = NativeModel(
+            num_blocks=int(num_blocks), block_size=int(block_size), max_num_seqs=max_num_seqs,
+            max_model_len=int(max_model_len), ctx_buckets=buckets,
+            weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0, quant_type=_QUANT_TYPES[qtype] if quantized else 0,
+            quantize_lm_head=int(quantized and not any("lm_head" in m for m in draft_skip)),
+            tp_degree=1, tp_rank=0, device_id=int(kwargs.get("device_id", 0)), use_graphs=int(cfg.get("use_graphs", 1)),
+            prefill_fp8_activations=int(bool(cfg.get("prefill_fp8_activations", False))), **geo)
+        synthetic, state_dict = cfg.get("draft_synthetic_weights"), cfg.get("draft_state_dict")
+        if synthetic is not None:
+            self.draft.init_synthetic_weights(int(synthetic.get("seed", 2)), float(synthetic.get("std", 0.02)))
+        elif state_dict is not None:
+            self.draft.load_state_dict(state_dict)
+        else:
+            target = self.model
+            try:
+                self.model = self.draft            # _load_safetensors_dir fills self.model
+                self._load_safetensors_dir(draft_cfg.model)
+            finally:
+                self.model = target
 
     @staticmethod
     def _artifact_dir(model_name_or_path, cfg, geo, quantized, qdtype, qtype, tp_degree):
@@ -364,8 +451,8 @@ def get_mi355x_model(model_config, cache_config, parallel_config, scheduler_conf
     _check_architecture(architecture)
     if lora_serving_config:
         raise NotImplementedError("Multi-lora is not yet supported on the MI355X plugin")
-    if speculative_config is not None:
-        raise NotImplementedError("Speculative decoding is not yet supported on the MI355X plugin")
+    if speculative_config is not None and getattr(speculative_config, "method", None) == "eagle":
+        raise NotImplementedError("EAGLE drafts are not supported on the MI355X plugin (plain draft models are)")
 
     model = MI355XCausalLM(model_config.hf_config)
     default_args = _get_default_mi355x_config(model_config, cache_config, parallel_config, scheduler_config,
@@ -380,9 +467,14 @@ def get_mi355x_model(model_config, cache_config, parallel_config, scheduler_conf
     cfg = _validate_mi355x_config(cache_config, scheduler_config, cfg)
     cfg["scheduler_max_num_seqs"] = scheduler_config.max_num_seqs
 
+    if cfg.get("enable_fused_speculation") and not cfg.get("on_device_sampling_config"):
+        # the fused step returns token ids, never logits (reference loader.py:349-355)
+        logger.info("fused speculation: on-device sampling switched on (the step returns accepted token ids)")
+        cfg["on_device_sampling_config"] = {"dynamic": True}
     model.load_weights(model_name_or_path=model_config.model, architecture=architecture, mi355x_config=cfg,
-                       **native_kwargs)
+                       speculative_config=speculative_config, **native_kwargs)
     cfg.pop("state_dict", None)
+    cfg.pop("draft_state_dict", None)
     model.mi355x_config = MI355XConfig(**{"attn_tkg_nki_kernel_enabled": False,
                                           "attn_block_tkg_nki_kernel_enabled": False,
                                           "chunked_prefill_config": None, **cfg})
@@ -410,7 +502,14 @@ def _get_default_mi355x_config(model_config, cache_config, parallel_config, sche
     if cache_config.num_gpu_blocks_override is not None:
         default_num_blocks = cache_config.num_gpu_blocks_override
 
+    speculation = {}
+    if speculative_config is not None:      # reference loader.py:785-791
+        speculation = {"enable_fused_speculation": True,
+                       "speculation_length": getattr(speculative_config, "num_speculative_tokens", 0)}
+        if getattr(speculative_config, "method", None) == "eagle":
+            speculation["enable_eagle_speculation"] = True
     return {
+        **speculation,
         "tp_degree": parallel_config.tensor_parallel_size,
         "ctx_batch_size": 1,
         "batch_size": batch_size,

@@ -137,10 +137,13 @@ class MI355XModelRunner:
         is where it is sized and allocated, once vLLM has decided the block count."""
         if self._kv_ready:
             return
-        native = self.model.model
-        if self.is_block_kv_layout and kv_cache_config is not None and getattr(kv_cache_config, "num_blocks", None):
-            native.set_num_blocks(int(kv_cache_config.num_blocks))
-        native.finalize()
+        # (with fused speculation the draft keeps a pool of its own under the same block ids)
+        for native in (self.model.model, getattr(self.model, "draft", None)):
+            if native is None:
+                continue
+            if self.is_block_kv_layout and kv_cache_config is not None and getattr(kv_cache_config, "num_blocks", None):
+                native.set_num_blocks(int(kv_cache_config.num_blocks))
+            native.finalize()
         self._kv_ready = True
 
     def _validate_sampling_configuration(self) -> None:
@@ -192,10 +195,16 @@ class MI355XModelRunner:
     def _generate_model_runner_output(self, sampler_outputs: SamplerOutput | None):
         if sampler_outputs is None:
             return EMPTY_MODEL_RUNNER_OUTPUT
+        sampled = sampler_outputs.sampled_token_ids
+        if self.speculative_config is not None and sampled.dim() == 3 and sampled.size(-1) == 1:
+            sampled = sampled.squeeze(-1)       # fused speculation: [B, T, 1] -> [B, T] (reference runner.py:310-312)
+        # -1 entries are pads (rows that produced no token, or the unused tail of a speculation
+        # window); 0 is a real token id
+        valid_sampled_token_ids = [[x for x in row if x != -1] for row in sampled.tolist()]
         if self.speculative_config is not None:
-            raise NotImplementedError("speculative decoding outputs are not supported on MI355X")
-        # -1 entries are pads (rows that produced no token); 0 is a real token id
-        valid_sampled_token_ids = [[x for x in row if x != -1] for row in sampler_outputs.sampled_token_ids.tolist()]
+            # what vLLM calls the speculated tokens of the step: all but the last one generated
+            # (reference runner.py:314-323)
+            self.spec_token_ids = [kept[:-1] if kept else [] for kept in valid_sampled_token_ids]
         for req_idx, sampled_ids in enumerate(valid_sampled_token_ids):
             if not sampled_ids:
                 continue
@@ -257,8 +266,11 @@ class MI355XModelRunner:
             self.input_batch.num_computed_tokens_cpu[req_index] = cached.num_computed_tokens[i]
             if new_block_ids is not None:
                 self.input_batch.block_table.append_row(new_block_ids, req_index)
-            if scheduler_output.scheduled_spec_decode_tokens.get(req_id, ()):
-                raise NotImplementedError("speculative tokens are not supported on MI355X")
+            spec_token_ids = scheduler_output.scheduled_spec_decode_tokens.get(req_id, ())
+            if spec_token_ids:      # draft tokens vLLM scheduled for verification (reference runner.py:488-498)
+                start = self.input_batch.num_tokens_no_spec[req_index]
+                self.input_batch.token_ids_cpu[req_index, start:start + len(spec_token_ids)] = spec_token_ids
+                self.input_batch.num_tokens[req_index] += len(spec_token_ids)
 
         for request in reqs_to_add:
             self.input_batch.add_request(request)
@@ -322,7 +334,7 @@ class MI355XModelRunner:
             tokens.append(state.output_token_ids[-1])
             positions.append(position)
             seq_ids.append(self.vllm_req_to_seq_id_mapping[req_id])
-            slots.append(block_table[position // bs] * bs + position % bs)
+            slots.append(self._decode_slots(block_table, position))
         for i in range(n, self.max_num_reqs):
             rows[i] = None
         pos_t = torch.tensor(positions, dtype=torch.long).reshape(n, 1)
@@ -330,9 +342,23 @@ class MI355XModelRunner:
         return ModelInputForMI355X(
             request_ids=list(req_ids), input_tokens=input_tokens, position_ids=pos_t,
             input_block_ids=torch.tensor(seq_ids, dtype=torch.long),
-            slot_mapping=torch.tensor(slots, dtype=torch.long).reshape(n, 1), block_tables=bt[:n],
+            slot_mapping=torch.tensor(slots, dtype=torch.long).reshape(n, -1), block_tables=bt[:n],
             full_context_lens=pos_t + 1, computed_context_lens=pos_t, prefill_completion_state=None,
             sampling_params=self._sampling_params_if_used(input_tokens), multi_modal_kwargs=None, adapter_ids=None)
+
+    def _decode_slots(self, block_table, position) -> list:
+        """K/V slot of the token fed to a token-generation step; with speculative decoding also the
+        slots of the speculated positions behind it (the reference appends consecutive slot numbers,
+        runner.py:825-830; here each position is looked up, so a window may cross a block boundary;
+        positions past the blocks the request owns get the pad and are never written)."""
+        bs = self.cache_config.block_size
+        n = 1 if self.speculative_config is None else max(int(self.speculative_config.num_speculative_tokens), 1)
+        out = []
+        for p in range(position, position + n):
+            blk = p // bs
+            out.append(block_table[blk] * bs + p % bs if blk < len(block_table) and p < self.max_model_len
+                       else self._SLOT_MAPPING_PAD)
+        return out
 
     # ---- chunked prefill (vLLM's native scheduler; reference runner.py:654-680, 938-1051) ----------
     def _prepare_chunked_prefill_inputs(self, scheduler_output) -> IntermediateInputData:
@@ -484,7 +510,7 @@ class MI355XModelRunner:
         data.block_tables.append(self._padded_block_table(block_table, pad))
         position = self._get_last_token_position(state)
         bs = self.cache_config.block_size
-        data.slot_mapping.append([block_table[position // bs] * bs + position % bs])
+        data.slot_mapping.append(self._decode_slots(block_table, position))
 
     def _finalize_continuous_batching_inputs(self, data: IntermediateInputData, is_prefill: bool):
         max_model_len = self.scheduler_config.max_model_len

@@ -106,6 +106,10 @@ class MI355XWorker(WorkerBase):
             st = native.kv_stats()
             usable = int(st["device_free_bytes"] * 0.95) - int(st["workspace_bytes"])
             per_block_all_layers = native.kv_bytes_per_block()
+            draft = getattr(self.model_runner.model, "draft", None)
+            if draft is not None:   # fused speculation: a second pool under the same block ids
+                per_block_all_layers += draft.kv_bytes_per_block()
+                usable -= int(draft.kv_stats()["workspace_bytes"])
             spec = self.model_runner.get_kv_cache_spec()["layer"]
             # the spec counts all kv heads of one layer; a shard holds its share of every layer
             blocks = max(usable, 0) // max(per_block_all_layers, 1)
