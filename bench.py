@@ -70,6 +70,12 @@ MODELS = {
         architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=128256, hidden_size=8192,
         intermediate_size=28672, num_hidden_layers=80, num_attention_heads=64, num_key_value_heads=8,
         head_dim=128, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=False, rope_scaling=LLAMA3_ROPE),
+    # draft model of the speculation section: Llama-3.2-1B dims (same vocabulary as the 8B target)
+    "llama32_1b": dict(
+        architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=128256, hidden_size=2048,
+        intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
+        head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=True,
+        rope_scaling={**LLAMA3_ROPE, "factor": 32.0}),
     # BASELINE config 1 (CPU plumbing): TinyLlama-1.1B dims, used by cpu_baseline only
     "tinyllama_1b": dict(
         architectures=["LlamaForCausalLM"], model_type="llama", vocab_size=32000, hidden_size=2048,
@@ -203,6 +209,61 @@ def cpu_baseline(hf, B, ctx, layers=2, steps=3):
             "ttft_ms_bucket_256": round(ttft_256 * 1e3, 1), "config1_cpu": config1}
 
 
+def speculation_section(torch, HF, wd, plain_ms, steps, k=4):
+    """One fused speculation step (mi_forward_spec: k chained draft steps + ONE target pass over the
+    B * k candidate rows + acceptance) timed next to its parts.  Weights are random, so NOTHING is
+    said about acceptance: the section reports what a step costs and how many tokens per sequence
+    it must yield on average to beat the plain step."""
+    from tests.helpers import decode_inputs
+    from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+    from vllm_neuron_amd.worker.mi355x_model_loader import _decoder_geometry
+    B, mb = MAX_NUM_SEQS, MAX_MODEL_LEN // BLOCK_SIZE
+    nb = 1 + B * mb
+
+    def build(hf, rows, seed):
+        m = NativeModel(num_blocks=nb, block_size=BLOCK_SIZE, max_num_seqs=rows, max_model_len=MAX_MODEL_LEN,
+                        ctx_buckets=BUCKETS, weight_dtype=MI_W[wd], quant_type=MI_Q["per_channel_symmetric"],
+                        quantize_lm_head=1, tp_degree=1, tp_rank=0, device_id=0, use_graphs=1,
+                        prefill_fp8_activations=0, **_decoder_geometry(SimpleNamespace(**hf)))
+        m.init_synthetic_weights(seed, 0.02)
+        m.finalize()
+        return m
+    target, draft = build(HF, B * k, 1), build(MODELS["llama32_1b"], B, 2)
+    blocks = [[1 + b * mb + j for j in range(mb)] for b in range(B)]
+    n = max(steps // 2, 8)
+
+    def replay(model, rows, row_pos, row_blocks):
+        model.forward(**decode_inputs([1] * rows, row_pos, row_blocks, BLOCK_SIZE, MAX_MODEL_LEN))
+        model.replay_decode(4)
+        return model.replay_decode(n) / n
+
+    def case(nb_):
+        bt = torch.tensor(blocks[:nb_], dtype=torch.long)
+        last, pos = torch.arange(1, nb_ + 1), torch.full((nb_,), DECODE_CTX - 1, dtype=torch.long)
+        for _ in range(3):
+            target.forward_spec(draft, last, pos, bt, k)
+        t = time.perf_counter()
+        for _ in range(n):
+            target.forward_spec(draft, last, pos, bt, k)
+        spec_ms = (time.perf_counter() - t) / n * 1e3
+        # the parts, device-resident: the target's pass over nb_ * k rows, one draft step, the plain step of nb_ rows
+        rows = nb_ * k
+        target_ms = replay(target, rows, [DECODE_CTX - 1 - (i % k) for i in range(rows)], [blocks[i // k] for i in range(rows)])
+        draft_ms = replay(draft, nb_, [DECODE_CTX - 1] * nb_, blocks[:nb_])
+        plain = plain_ms if nb_ == B else replay(target, nb_, [DECODE_CTX - 1] * nb_, blocks[:nb_])
+        return {"B": nb_, "spec_step_ms": round(spec_ms, 4), "target_pass_ms_over_B_times_k_rows": round(target_ms, 4),
+                "draft_step_ms": round(draft_ms, 4), "plain_step_ms": round(plain, 4),
+                "tokens_per_sequence_and_step_to_break_even": round(spec_ms / plain, 3),
+                "tokens_per_s_if_all_k_accepted": round(nb_ * k / (spec_ms * 1e-3), 1)}
+    cases = [case(B), case(1)]
+    draft.close()
+    target.close()
+    return {"k": k, "draft": f"Llama-3.2-1B dims, {wd}, synthetic", "cases": cases,
+            "note": "spec_step_ms: host-timed calls (inputs H2D, k + 1 graph launches, accepted ids D2H); the other times are "
+                    "graph replays with resident inputs.  Random weights: no acceptance rate is claimed -- "
+                    "tests/test_spec_decode_gpu.py checks that the text equals the target's greedy text"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +272,7 @@ def main():
     ap.add_argument("--model", default="llama31_8b", choices=["llama31_8b", "qwen25_7b", "llama33_70b"])
     ap.add_argument("--ttft-prompts", type=int, default=32, help="prompts per context-encoding bucket (p50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-speculation", action="store_true", help="skip the fused-speculation timing section")
     ap.add_argument("--weight-dtype", default=None, choices=["f8e4m3", "int8", "bf16"],
                     help="default: f8e4m3 (int8 for qwen25_7b)")
     ap.add_argument("--tp-transport", default="p2p", choices=["p2p", "rccl"])
@@ -431,6 +493,11 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "traffic": None, "step_algorithmic_GB": round(step_bytes / 1e9, 3)}
 
+    # ---- fused speculation (SURVEY 8f-4 tail): what a speculation step costs next to a plain step --------
+    speculation = None
+    if tp == 1 and args.model == "llama31_8b" and wd != "bf16" and not args.no_speculation:
+        speculation = speculation_section(torch, HF, wd, ms_per_step, args.steps)
+
     cpu = None
     if tp == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(MODELS["llama31_8b"] if args.model != "qwen25_7b" else HF, MAX_NUM_SEQS, DECODE_CTX)
@@ -460,6 +527,7 @@ def main():
         "device_ms_per_step": round(dev_ms / args.steps, 4),
         "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
         "pcie_inclusive_tokens_per_s": round(MAX_NUM_SEQS / e2e, 2),
+        "speculation": speculation,
         "init_s": round(init_s, 2), "roofline": roofline, "cpu_baseline": cpu,
     }
     finish(line)
