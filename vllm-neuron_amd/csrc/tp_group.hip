@@ -492,15 +492,15 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
 // ramp), every rank must end with the same exact sums.  Run once after the exchange buffers
 // exist; the caller falls back to RCCL when the peer-memory path does not deliver (a fabric /
 // driver configuration this code has never met), instead of failing at the first model call.
-static int selftest_rank(mi_ctx* c, size_t n) {
+static int selftest_rank(mi_ctx* c, size_t n, int it) {
   mi_group* g = c->grp;
   const int T = g->T, r = c->cfg.tp_rank;
-  // PINNED staging + copies on the shard's own stream: a copy from pageable memory is staged by the
-  // runtime outside the order of a non-blocking stream (seen: its tail landing behind the reduce and
-  // restoring the rank's own input from the second page on)
+  // pinned staging, copies on the shard's own stream.  The ramp moves with the iteration, so a slot
+  // that still shows an earlier exchange (a stale cache line) does not add up to this one's sums.
+  auto ramp = [it](size_t i) { return (float)((i + 7 * (size_t)it) % 31) * 0.25f; };
   float* h = nullptr;
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&h), n * 4, hipHostMallocDefault));
-  for (size_t i = 0; i < n; ++i) h[i] = (float)(r + 1) + (float)(i % 61) * 0.25f;   // exact in bf16 too
+  for (size_t i = 0; i < n; ++i) h[i] = (float)(r + 1) + ramp(i);   // exact in bf16 too (T = 2, 4, 8, 16)
   int rc = MI_OK;
   if (hipMemcpyAsync(c->partial, h, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = MI_EHIP;
   if (rc == MI_OK) rc = group_all_reduce(c, c->partial, n);
@@ -513,7 +513,7 @@ static int selftest_rank(mi_ctx* c, size_t n) {
     return rc;
   }
   for (size_t i = 0; i < n; ++i) {
-    const float want = (float)(T * (T + 1) / 2) + (float)T * (float)(i % 61) * 0.25f;
+    const float want = (float)(T * (T + 1) / 2) + (float)T * ramp(i);
     if (h[i] != want) {
       std::string dbg;
       if (!g->use_rccl) {
@@ -527,7 +527,7 @@ static int selftest_rank(mi_ctx* c, size_t n) {
           dbg += " " + std::to_string(v[0]) + "/" + std::to_string(v[1]);
         }
         size_t bad = 0, last = i;
-        for (size_t j = i; j < n; ++j) if (h[j] != (float)(T * (T + 1) / 2) + (float)T * (float)(j % 61) * 0.25f) { ++bad; last = j; }
+        for (size_t j = i; j < n; ++j) if (h[j] != (float)(T * (T + 1) / 2) + (float)T * ramp(j)) { ++bad; last = j; }
         dbg += " bad " + std::to_string(bad) + " last " + std::to_string(last) + " cap " + std::to_string(g->cap);
       }
       set_error("tensor-parallel exchange self-test (" + std::to_string(n) + " elements): rank " + std::to_string(r) +
@@ -544,13 +544,15 @@ int group_selftest(mi_group* g) {
   auto run = [&]() {
     // a token-generation sized message (one-shot) and, when the slots allow, a context-encoding sized one (two-shot)
     int rc = MI_OK;
-    const int iters = getenv("MI355X_ST_ITERS") ? atoi(getenv("MI355X_ST_ITERS")) : 2;   // both slots of the double buffer
+    // each slot of the double buffers is used, then REUSED with other data (a reader that still holds the
+    // line of two exchanges ago fails the second round)
+    const int iters = getenv("MI355X_ST_ITERS") ? atoi(getenv("MI355X_ST_ITERS")) : 4;
     for (int it = 0; it < iters && rc == MI_OK; ++it) {
-      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->use_rccl ? (size_t)c->max_rows * c->H : g->cap, 4 * 4096)); });
+      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->use_rccl ? (size_t)c->max_rows * c->H : g->cap, 4 * 4096), it); });
       if (rc != MI_OK) fprintf(stderr, "[mi355x] self-test failed at iteration %d\n", it);
     }
-    if (rc == MI_OK && !g->use_rccl && g->cap >= kArTwoShotBytes)
-      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->cap, kArTwoShotBytes) / 8 * 8); });
+    for (int it = 0; it < iters && rc == MI_OK && !g->use_rccl && g->cap >= kArTwoShotBytes; ++it)
+      rc = group_run(g, [&](mi_ctx* c, int) { return selftest_rank(c, std::min<size_t>(g->cap, kArTwoShotBytes) / 8 * 8, iters + it); });
     return rc;
   };
   int rc = run();
