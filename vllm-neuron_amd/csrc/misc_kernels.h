@@ -31,5 +31,8 @@ int launch_fill_f32(float* out, size_t n, float v, hipStream_t s);
 // On-device sampling over fp32 logits rows (vocab-parallel segments [T][row_stride][V_l]); params
 // [B,3] = (top_k, top_p, temperature) per row, null = greedy; tokens[B] int32 (device).
 int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int B, const float* params,
-                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s);
+                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s, void* scratch = nullptr);
+// scratch: sample_scratch_bytes(rows) of device memory; with it and params == nullptr (every row greedy) the argmax is
+// split over the chip (two small launches instead of one work-group per row)
+size_t sample_scratch_bytes(int max_rows);
 }  // namespace mi

@@ -363,9 +363,66 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   }
 }
 
+// ---- all rows greedy: argmax split over the chip -------------------------------------------------
+// One work-group per row walks a 128k vocabulary in ~50 us; kArgmaxSplits work-groups per row take ~3 us,
+// a second launch merges their (value, index) pairs -- same rule as the one-work-group form: the
+// largest logit, ties to the lowest vocabulary index, an all-NaN row gives token 0.
+constexpr int kArgmaxSplits = 64;
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ logits, int T, int row_stride, int V_l,
+                                                             float* __restrict__ part_v, int32_t* __restrict__ part_i) {
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  const int b = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+  const int V = T * V_l, per = ceil_div(V, kArgmaxSplits);
+  const int v0 = sp * per, v1 = min(v0 + per, V);
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = v0 + tid; v < v1; v += 256) {
+    const float x = logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)];
+    if (x > bv) { bv = x; bi = v; }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+    part_v[b * kArgmaxSplits + sp] = bv;
+    part_i[b * kArgmaxSplits + sp] = bi;
+  }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ part_v, const int32_t* __restrict__ part_i,
+                                                          int32_t* __restrict__ tokens) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float bv = part_v[b * kArgmaxSplits + lane];
+  int bi = part_i[b * kArgmaxSplits + lane];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) tokens[b] = bi == 0x7fffffff ? 0 : bi;
+}
+static_assert(kArgmaxSplits == 64, "argmax_final_kernel merges one partial per lane of one wave");
+size_t sample_scratch_bytes(int max_rows) { return (size_t)max_rows * kArgmaxSplits * 8; }
+
 int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int B, const float* params,
-                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s) {
+                       unsigned long long seed, int row0, int32_t* tokens, hipStream_t s, void* scratch) {
   MI_CHECK(B >= 1 && T >= 1 && V_l >= 1, "sample: bad shape");
+  if (!params && scratch) {   // every row greedy and the caller has room for the partials
+    float* pv = reinterpret_cast<float*>(scratch);
+    int32_t* pi = reinterpret_cast<int32_t*>(pv + (size_t)B * kArgmaxSplits);
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(kArgmaxSplits, B), dim3(256), 0, s, logits, T, row_stride, V_l, pv, pi);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(B), dim3(64), 0, s, pv, pi, tokens);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(kSampleThreads), 0, s, logits, T, row_stride, V_l, params,
                      seed, row0, tokens);
   MI_HIP(hipGetLastError());

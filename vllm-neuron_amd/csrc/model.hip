@@ -630,7 +630,7 @@ int mi_ctx_destroy(mi_ctx* c) {
   fl(c->lm_head);
   void* ptrs[] = {c->g_final, c->embed, c->rowmax, c->kv_pool, c->rope_cos, c->rope_sin, c->stage_raw, c->stage_f32,
                   c->resid[0], c->resid[1], c->partial, c->xn, c->qbuf, c->attn_out, c->act, c->logits, c->logits_all,
-                  c->attn_scratch, c->d_inputs, c->d_dec, c->d_dec_bt, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws, c->d_spec};
+                  c->attn_scratch, c->d_inputs, c->d_dec, c->d_dec_bt, c->d_sparams, c->d_tokens, c->x8, c->x8_scale, c->splitk_ws, c->d_spec, c->d_sample_scratch};
   for (void* p : ptrs) hipFree(p);
   void* hptrs[] = {c->h_inputs, c->h_dec, c->h_dec_bt, c->h_sparams, c->h_tokens, c->h_logits, c->h_spec};
   for (void* p : hptrs) if (p) hipHostFree(p);
@@ -989,6 +989,11 @@ int mi_finalize(mi_ctx* c) {
   }
   MI_TRY(dmalloc(&c->d_sparams, (size_t)k.max_num_seqs * 3, ws));
   MI_TRY(dmalloc(&c->d_tokens, (size_t)k.max_num_seqs, ws));
+  {
+    unsigned char* p = nullptr;
+    MI_TRY(dmalloc(&p, sample_scratch_bytes(k.max_num_seqs), ws));
+    c->d_sample_scratch = p;
+  }
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_sparams), (size_t)k.max_num_seqs * 3 * 4, hipHostMallocDefault));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tokens), (size_t)k.max_num_seqs * 4, hipHostMallocDefault));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), (size_t)k.max_num_seqs * k.vocab_size * 4, hipHostMallocDefault));
@@ -1084,15 +1089,18 @@ static int sample_on_device(mi_ctx* c, int nrows, int row0, const float* samplin
     if (k.tp_rank != 0) return MI_OK;
   }
   const float* dparams = nullptr;
-  if (sampling_params) {
+  bool all_greedy = true;   // (top_k = 1 rows draw nothing: the split argmax serves the whole batch)
+  if (sampling_params)
+    for (int i = 0; i < nrows; ++i) all_greedy = all_greedy && sampling_params[(size_t)(row0 + i) * 3] == 1.f;
+  if (sampling_params && !all_greedy) {
     memcpy(c->h_sparams, sampling_params + (size_t)row0 * 3, (size_t)nrows * 3 * 4);
     MI_HIP(hipMemcpyAsync(c->d_sparams, c->h_sparams, (size_t)nrows * 3 * 4, hipMemcpyHostToDevice, s));
     dparams = c->d_sparams;
   }
   {
     Scope sc(c, MI_K_OTHER);
-    if (c->collective()) MI_TRY(launch_sample_rows(c->logits_all, k.tp_degree, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s));
-    else MI_TRY(launch_sample_rows(c->logits, 1, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s));
+    if (c->collective()) MI_TRY(launch_sample_rows(c->logits_all, k.tp_degree, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s, c->d_sample_scratch));
+    else MI_TRY(launch_sample_rows(c->logits, 1, k.max_num_seqs, c->V_l, nrows, dparams, seed, row0, c->d_tokens, s, c->d_sample_scratch));
   }
   MI_HIP(hipMemcpyAsync(c->h_tokens, c->d_tokens, (size_t)nrows * 4, hipMemcpyDeviceToHost, s));
   g_ht.lap(3);
@@ -1338,13 +1346,13 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   for (int step = 0; step < k; ++step) {
     MI_TRY(capture_or_launch_decode(d, B, MB));
     if (step + 1 < k) {
-      MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s));
+      MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s, d->d_sample_scratch));
       MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
                                  d_cand, s));
     }
   }
   MI_TRY(capture_or_launch_decode(t, B * k, MB));
-  MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s));
+  MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s, t->d_sample_scratch));
   MI_TRY(launch_spec_accept(B, k, t->d_tokens, d_cand, d_limit, d_pos0, d_out, d_out + ms, s));
   MI_HIP(hipMemcpyAsync(h_out, d_out, 2 * ms * 4, hipMemcpyDeviceToHost, s));   // out + next_pos (adjacent)
   MI_HIP(hipStreamSynchronize(s));
