@@ -94,6 +94,31 @@ def test_qlinear(lib, wd, M, path, N, K):
     assert err < tol, (err, tol)
 
 
+@pytest.mark.parametrize("wd", ["f8e4m3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(3, 272, 28672), (5, 272, 28672), (8, 528, 28672), (9, 272, 28672), (13, 272, 28672),
+                                   (16, 4096, 28672), (4, 3584, 18944), (7, 272, 18944), (6, 272, 14336), (16, 4096, 14336)])
+def test_qlinear_activations_streamed_beside_the_weights(lib, wd, M, N, K):
+    """bf16 activations too large for the LDS (rows x K): gemv_kstream_kernel stages each wave's K-slice
+    by LDS-DMA, 16 / 8 / 4 k-tiles per sub-chunk for up to 4 / 8 / 16 rows; ragged K-slices
+    (28672 / 64 = 448 k-tiles = 8 x 56; 18944 / 64 = 296 = 8 x 37; bf16 weights: 32-wide k-tiles),
+    more row-tiles than CUs (N = 4096 at 256 CUs is exactly one each; 528 rows = 33 tiles)."""
+    torch.manual_seed(4)
+    w = torch.randn(N, K) * 0.05
+    x = torch.randn(M, K).to(torch.bfloat16)
+    bias = torch.randn(N) * 0.1
+    tiled, scale = quantize_on_device(lib, w, wd, "per_channel_symmetric")
+    wq = w.to(torch.bfloat16).float() if wd == "bf16" else dequantize_weight(*quantize_weight(w, wd, "per_channel_symmetric"))
+    ref = x.float().double() @ wq.double().t() + bias.double()
+    y = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    xd, bd = dev(x), dev(bias)
+    lib.check(lib.load_library().mi_op_qlinear(xd.data_ptr(), M, tiled.data_ptr(), scale.data_ptr(), bd.data_ptr(),
+                                               N, K, WD[wd], y.data_ptr(), 1, None))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    tol = 2e-5 * ref.abs().max().item() + 1e-5 * (K ** 0.5)
+    assert err < tol, (err, tol)
+
+
 @pytest.mark.parametrize("M", [17, 128, 200, 300])
 @pytest.mark.parametrize("N,K", [(576, 384), (1024, 4096), (256, 14336)])
 def test_qlinear_fp8_activations(lib, M, N, K):

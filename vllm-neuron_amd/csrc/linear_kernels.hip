@@ -838,6 +838,15 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_priv_kernel(const uint4*
   MI_TRACE_END();
 }
 
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses into 1 KiB of LDS starting at `l` (wave-uniform)
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+static bool gemv_kstream_enabled() {
+  static const bool on = [] { const char* v = getenv("MI355X_GEMV_KSTREAM"); return !(v && v[0] == '0'); }();
+  return on;
+}
 static bool gemv_priv_enabled() {
   static const bool on = [] { const char* v = getenv("MI355X_GEMV_PRIV"); return !(v && v[0] == '0'); }();
   return on;
@@ -910,10 +919,23 @@ static int launch_gemv_ks(const LinearW& w, int M, int TP, const ProArgs& p, con
 
 template <int WD, int PRO, int EPI>
 static int launch_gemv_bigk_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s);
+template <int WD, int EPI>
+static int launch_gemv_kstream(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s);
 
 template <int WD, int PRO, int EPI>
 static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
-  if (!gemv_fits_whole(M, w.K)) return launch_gemv_bigk_t<WD, PRO, EPI>(w, M, p, e, s);
+  if (!gemv_fits_whole(M, w.K)) {
+    if constexpr (PRO == PRO_BF16 && (EPI == EPI_F32 || EPI == EPI_RESID)) {
+      static const int min_m = [] { const char* v = getenv("MI355X_GEMV_KSTREAM_MIN_M"); return v ? atoi(v) : 1; }();
+      if (gemv_kstream_enabled() && M >= min_m) return launch_gemv_kstream<WD, EPI>(w, M, p, e, s);
+    }
+    return launch_gemv_bigk_t<WD, PRO, EPI>(w, M, p, e, s);
+  }
+  if constexpr (PRO == PRO_BF16 && (EPI == EPI_F32 || EPI == EPI_RESID)) {
+    // experiment knob: rows from which the streamed form also replaces the whole-image kernels
+    static const int all_m = [] { const char* v = getenv("MI355X_GEMV_KSTREAM_ALL_M"); return v ? atoi(v) : 1 << 30; }();
+    if (gemv_kstream_enabled() && M >= all_m && w.K / tile_k(WD) >= 2 * kGemvWaves) return launch_gemv_kstream<WD, EPI>(w, M, p, e, s);
+  }
   int num_cu = 0;
   MI_TRY_(device_num_cu(&num_cu));
   const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
@@ -1121,6 +1143,182 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_bigk_kernel(const uint4*
     if (i + 1 < total) process(bufB, i + 1);
     issue(bufB, i + 3);
   }
+}
+
+// =====================================================================================
+// GEMV, activations streamed beside the weights (bf16 activations that do not fit the LDS whole)
+// =====================================================================================
+// gemv_bigk_kernel stages a K-chunk of the activations for all waves, meets, multiplies, meets again: the
+// weight stream stalls at every chunk (Qwen2.5-7B down_proj, K = 18944 at 4 rows: 22.8 us for 68 MB;
+// Llama-8B down_proj at 16 rows, the target's pass of a speculation step: 35 us for 59 MB).  The K
+// dimension of a row-tile is split over the 8 waves as everywhere, so a wave only ever multiplies ITS
+// K-slice: here it also stages that slice for itself, a sub-chunk of U k-tiles at a time, by LDS-DMA
+// (global_load_lds: no registers, no arithmetic -- hence bf16 activations only) into a double buffer of
+// its own, two sub-chunks ahead together with the weight batch of the same k-tiles.  No work-group
+// barrier before the K-slice reduction of a row-tile.  The lane -> source-address map of the DMA does
+// the transpose into the MFMA B-fragment image (xfrag_slot: [k-chunk][row] 16-byte slots); a sub-chunk is always
+// 4 or 8 DMA instructions (U = 8 / 8 / 4 k-tiles for up to 4 / 8 / 16 rows), so the waits are
+// counted at compile time.  Same K-slices and MFMA order as gemv_bigk_kernel's chunks of one wave:
+// the products differ from it only in the association of the per-wave partial sums (none: each wave
+// still adds its k-tiles in order, the waves are combined in wave order).
+constexpr int kKsBuf = 8 * 1024;                   // bytes of one wave-private activation buffer (<= 8 DMA instructions)
+static size_t gemv_kstream_lds() { return (size_t)kGemvWaves * 2 * kKsBuf + 2 * kGemvWaves * 64 * 16 + 64 * 4 + 16; }
+
+template <int WD, int EPI, int U, int kKsDma>   // U k-tiles and kKsDma DMA instructions (64 slots each) per sub-chunk
+__global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uint4* __restrict__ W, int NT, int KT, int M,
+                                                                       int K, int G, ProArgs p, EpiArgs e) {
+  constexpr int TK = (WD == MI_W_BF16) ? 32 : 64;
+  constexpr int QPT = TK / 8;                      // 16-byte activation slots per k-tile and row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const bool col_ok = c < M;
+  unsigned char* xb = smem + (size_t)wave * 2 * kKsBuf;
+  unsigned char* tail = smem + (size_t)kGemvWaves * 2 * kKsBuf;
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);                       // [2 parities][8 waves][64 lanes]
+  float* sc_lds = reinterpret_cast<float*>(tail + 2 * kGemvWaves * 64 * 16);   // [2 parities][scale 16 | bias 16]
+  uint4* zero = reinterpret_cast<uint4*>(sc_lds + 64);
+  pin_sgpr(W); pin_sgpr(NT); pin_sgpr(KT); pin_sgpr(M); pin_sgpr(K); pin_sgpr(G); pin_sgpr(p.x); pin_sgpr(p.ldx);
+  pin_sgpr(e.scale); pin_sgpr(e.bias); pin_sgpr(e.out_f32); pin_sgpr(e.ld_out);
+  if constexpr (EPI == EPI_RESID) pin_sgpr(e.resid_in);
+
+  const int ktw = ceil_div(KT, kGemvWaves);            // k-tiles per wave
+  const int kbeg = min(wave * ktw, KT), kend = min(kbeg + ktw, KT);
+  const int nsc = ceil_div(ktw, U);                    // sub-chunks per row-tile, the same for every wave
+  const int my_tiles = (int)blockIdx.x < NT ? ceil_div(NT - (int)blockIdx.x, G) : 0;
+  const int total = my_tiles * nsc;
+  const int slots = U * QPT * M;                       // live 16-byte slots of a sub-chunk (<= 64 kKsDma)
+
+  // lane -> (k offset, row) of its slot in each of the 8 DMA instructions of a sub-chunk (fixed)
+  int src_off[kKsDma], src_k[kKsDma];                  // element offset inside the sub-chunk's [rows][U * TK] window (-1: no slot), its k part
+#pragma unroll
+  for (int d = 0; d < kKsDma; ++d) {
+    const int sl = d * 64 + lane, q = sl / M, r = sl - q * M;
+    // slot q of the image holds the 8-element chunk xfrag_slot maps there: inside a 64-wide k-tile the
+    // chunks are interleaved (slot (h, g) <- chunk 2 g + h) to match the byte order of the 1-byte weight tiles
+    int ch = q;
+    if constexpr (WD != MI_W_BF16) ch = (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1);
+    src_off[d] = sl < slots ? r * p.ldx + ch * 8 : -1;
+    src_k[d] = ch * 8;
+  }
+  auto issue_x = [&](int sel, int i) {
+    const bool live = i < total;
+    const int j = live ? i % nsc : 0;
+    const int k0 = (kbeg + j * U) * TK;                // first element of the sub-chunk
+    const int klim = kend * TK;
+#pragma unroll
+    for (int d = 0; d < kKsDma; ++d) {
+      // a slot past the wave's slice (or no slot at all) fetches the first line of x: never multiplied
+      const int off = src_off[d];
+      const bool ok = live && off >= 0 && k0 + src_k[d] < klim;
+      glds16(p.x + (ok ? (size_t)k0 + off : 0), xb + sel * kKsBuf + d * 1024);
+    }
+  };
+  u32x4_t bufA[U], bufB[U];
+  auto issue_w = [&](u32x4_t (&buf)[U], int i) {
+    const bool live = i < total && kbeg < kend;
+    const int ii = min(i, max(total - 1, 0));
+    const int it = ii / nsc, j = ii - it * nsc;
+    const int tile = min((int)blockIdx.x + it * G, NT - 1);
+    const int klast = max(kend - 1, kbeg);
+    const uint4* base = live ? W + (size_t)tile * KT * 64 + lane : W;
+    const size_t kstep = live ? 64 : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) stream_load16(buf[u], base + (size_t)min(kbeg + j * U + u, min(klast, KT - 1)) * kstep);
+  };
+
+  if (tid == 0) *zero = make_uint4(0, 0, 0, 0);
+  issue_x(0, 0);
+  issue_w(bufA, 0);
+  issue_x(1, 1);
+  issue_w(bufB, 1);
+  float scv = 0.f, biv = 0.f;                          // scale / bias of the row-tile in flight (threads 0..15)
+  __syncthreads();                                     // the zero slot
+
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int parity = 0;
+  auto process = [&](u32x4_t (&buf)[U], int sel, int i) {
+    const int it = i / nsc, j = i - it * nsc;
+    const int tile = (int)blockIdx.x + it * G;
+    if (j == 0 && tid < 16) {
+      scv = e.scale[tile * 16 + tid];
+      biv = e.bias ? e.bias[tile * 16 + tid] : 0.f;
+    }
+    // everything but the DMAs and weight loads of the NEXT sub-chunk has landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKsDma + U) : "memory");
+    const uint4* xf = reinterpret_cast<const uint4*>(xb + sel * kKsBuf);
+    const int kt0 = kbeg + j * U;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = col_ok && kt0 + u < kend;
+      const u32x4_t w = buf[u];
+      if constexpr (WD == MI_W_BF16) {
+        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, ok ? xf[(u * 4 + g) * M + c] : *zero);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), bb, acc, 0, 0, 0);
+      } else {
+        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, ok ? xf[((u * 2 + 0) * 4 + g) * M + c] : *zero);
+        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, ok ? xf[((u * 2 + 1) * 4 + g) * M + c] : *zero);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
+      }
+    }
+    if (j == nsc - 1) {   // row-tile done: combine the K-slices in wave order
+      red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
+      if (tid < 16) { sc_lds[parity * 32 + tid] = scv; sc_lds[parity * 32 + 16 + tid] = biv; }
+      __syncthreads();
+      if (wave == 0 && col_ok && tile < NT) {
+        f32x4_t sacc = red[(parity * kGemvWaves) * 64 + lane];
+#pragma unroll
+        for (int w2 = 1; w2 < kGemvWaves; ++w2) {
+          const f32x4_t t = red[(parity * kGemvWaves + w2) * 64 + lane];
+          sacc[0] += t[0]; sacc[1] += t[1]; sacc[2] += t[2]; sacc[3] += t[3];
+        }
+        epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc_lds + parity * 32 + g * 4,
+                          e.bias ? sc_lds + parity * 32 + 16 + g * 4 : nullptr, sacc, 1.f);
+      }
+      parity ^= 1;
+      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // the buffer is re-filled next: its fragment reads must have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int i = 0; i < total; i += 2) {
+    process(bufA, 0, i);
+    issue_x(0, i + 2);
+    issue_w(bufA, i + 2);
+    if (i + 1 < total) {
+      process(bufB, 1, i + 1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kKsDma + U) : "memory");   // keep the DMA / wait pairing of the loop
+    }
+    issue_x(1, i + 3);
+    issue_w(bufB, i + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the work-group has gone
+}
+
+template <int WD, int EPI, int U, int ND>
+static int launch_gemv_kstream_u(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  const int NT = w.N / 16, KT = w.K / tile_k(WD);
+  MI_CHECK(U * (tile_k(WD) / 8) * M <= ND * 64, "gemv_kstream: sub-chunk larger than its DMA budget");
+  auto kern = gemv_kstream_kernel<WD, EPI, U, ND>;
+  MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
+  int num_cu = 0;
+  MI_TRY_(device_num_cu(&num_cu));
+  int grid = NT;
+  if (NT > num_cu) grid = ceil_div(NT, ceil_div(NT, num_cu));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), gemv_kstream_lds(), s, reinterpret_cast<const uint4*>(w.w), NT,
+                     KT, M, w.K, grid, p, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+template <int WD, int EPI>
+static int launch_gemv_kstream(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  MI_CHECK(p.ldx % 8 == 0, "gemv: activation row stride must be a multiple of 8 elements");
+  if (M <= 4) return launch_gemv_kstream_u<WD, EPI, 8, 4>(w, M, p, e, s);
+  if (M <= 8) return launch_gemv_kstream_u<WD, EPI, 8, 8>(w, M, p, e, s);
+  return launch_gemv_kstream_u<WD, EPI, 4, 8>(w, M, p, e, s);
 }
 
 template <int WD, int PRO, int EPI>
@@ -1357,10 +1555,6 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
 // ONE raw barrier per K-step -- no ordinary global load in the loop, so hipcc has nothing to drain.
 constexpr int kWideBN = 256, kWideWBytes = 16 * 1024, kWideStages = 3;
 
-__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 
 // BM = 128: waves 2 (tokens) x 4 (weight rows), each 64 x 64.  BM = 256: each 128 x 64 (128 accumulator
 // registers): 16 + 32 KiB per K-step for 8.4 MFLOP -- the kernel is bound by what a CU can take in
