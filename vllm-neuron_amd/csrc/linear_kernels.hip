@@ -931,11 +931,8 @@ static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArg
     }
     return launch_gemv_bigk_t<WD, PRO, EPI>(w, M, p, e, s);
   }
-  if constexpr (PRO == PRO_BF16 && (EPI == EPI_F32 || EPI == EPI_RESID)) {
-    // experiment knob: rows from which the streamed form also replaces the whole-image kernels
-    static const int all_m = [] { const char* v = getenv("MI355X_GEMV_KSTREAM_ALL_M"); return v ? atoi(v) : 1 << 30; }();
-    if (gemv_kstream_enabled() && M >= all_m && w.K / tile_k(WD) >= 2 * kGemvWaves) return launch_gemv_kstream<WD, EPI>(w, M, p, e, s);
-  }
+  // (measured: replacing the whole-image kernels by the streamed form wherever the activations are bf16 gains
+  //  nothing at 16 rows and loses at 8 and 4 -- 2.72 vs 2.67 ms and 2.29 vs 2.14 ms per Llama-8B pass)
   int num_cu = 0;
   MI_TRY_(device_num_cu(&num_cu));
   const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
