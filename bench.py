@@ -210,7 +210,7 @@ def cpu_baseline(hf, B, ctx, layers=2, steps=3):
 
 
 def speculation_section(torch, HF, wd, plain_ms, steps, k=4):
-    """One fused speculation step (mi_forward_spec: k chained draft steps + ONE target pass over the
+    """One fused speculation step (mi_forward_spec: k - 1 chained draft steps + ONE target pass over the
     B * k candidate rows + acceptance) timed next to its parts.  Weights are random, so NOTHING is
     said about acceptance: the section reports what a step costs and how many tokens per sequence
     it must yield on average to beat the plain step."""
@@ -228,7 +228,7 @@ def speculation_section(torch, HF, wd, plain_ms, steps, k=4):
         m.init_synthetic_weights(seed, 0.02)
         m.finalize()
         return m
-    target, draft = build(HF, B * k, 1), build(MODELS["llama32_1b"], B, 2)
+    target, draft = build(HF, B * k, 1), build(MODELS["llama32_1b"], 2 * B, 2)
     blocks = [[1 + b * mb + j for j in range(mb)] for b in range(B)]
     n = max(steps // 2, 8)
 
@@ -259,7 +259,7 @@ def speculation_section(torch, HF, wd, plain_ms, steps, k=4):
     draft.close()
     target.close()
     return {"k": k, "draft": f"Llama-3.2-1B dims, {wd}, synthetic", "cases": cases,
-            "note": "spec_step_ms: host-timed calls (inputs H2D, k + 1 graph launches, accepted ids D2H); the other times are "
+            "note": "spec_step_ms: host-timed calls (inputs H2D, k graph launches, accepted ids D2H; no catch-up row); the other times are "
                     "graph replays with resident inputs.  Random weights: no acceptance rate is claimed -- "
                     "tests/test_spec_decode_gpu.py checks that the text equals the target's greedy text"}
 

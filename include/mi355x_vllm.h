@@ -168,20 +168,24 @@ int mi_forward_chunked(mi_ctx* ctx, int32_t n_req, int32_t total, const int64_t*
 
 /* Fused speculation (the reference reaches it through NxDI's fused draft + target graph:
  * loader.py:349-355; output contract re-masked by _remask_fused_spec_output, loader.py:308-333; slots
- * of the speculated positions, runner.py:825-830).  One call = `k` greedy token-generation steps of
+ * of the speculated positions, runner.py:825-830).  One call = `k - 1` greedy token-generation steps of
  * the DRAFT context chained on the device, ONE token-generation pass of the TARGET context over the
  * B * k candidate rows, greedy acceptance.  input_ids / position_ids [B]: the last accepted token
  * of every sequence and its position; block_table [B, MB] must back positions up to
  * position + k - 1 (clipped at max_model_len) in BOTH contexts (same block ids, separate pools).
  * accepted_out [B, k]: the 1..k tokens generated this step, 0-padded (NxDI's
  * accepted_tokens_with_padding); next_pos_out [B] = position + number of tokens generated.  The
- * tokens are exactly those the target alone would generate greedily, one per step.  Needs
- * target max_num_seqs >= B * k, draft max_num_seqs >= B, and both contexts created with the same
+ * tokens are exactly those the target alone would generate greedily, one per step.
+ * draft_catchup_ids [B] or NULL: the draft runs k - 1 steps, so after a step that generated k tokens
+ * the token at position - 1 has not been through the draft; pass it here (-1 = nothing to catch up)
+ * and the draft's first step takes it as an extra row.  Leaving it out never changes the output,
+ * only the quality of the draft's proposals.  Needs
+ * target max_num_seqs >= B * k, draft max_num_seqs >= B + catch-up rows (2 B), and both contexts created with the same
  * device, block_size, num_blocks, vocab_size and max_model_len; TP = 1.  From the first call on the
  * draft context runs on the target's stream: destroy the draft before the target. */
 int mi_forward_spec(mi_ctx* target, mi_ctx* draft, int32_t B, int32_t k, const int64_t* input_ids,
-                    const int64_t* position_ids, const int64_t* block_table, int32_t MB, int64_t* accepted_out,
-                    int64_t* next_pos_out);
+                    const int64_t* position_ids, const int64_t* block_table, int32_t MB,
+                    const int64_t* draft_catchup_ids, int64_t* accepted_out, int64_t* next_pos_out);
 
 /* Replay the LAST token-generation call `steps` times with its inputs left resident in HBM
  * (no host round trip in between) and return the elapsed time measured with HIP events on the

@@ -53,7 +53,10 @@ def fused_speculation_step(target: PagedDecoderOracle, draft: PagedDecoderOracle
         pos, row = int(positions[b]), block_table[b]
         lim = min(k, max_model_len - pos)                      # candidate rows that fit the model length
         cand = [int(last_tokens[b])]
-        for i in range(lim):                                    # the draft runs every step: its K/V covers all acceptable tokens
+        # the draft sees every candidate here; the HIP path runs k - 1 draft steps and feeds the last candidate
+        # to the draft at the start of the NEXT step when (and only when) it was accepted -- the same K/V
+        # wherever it is ever read
+        for i in range(lim):
             logits = draft.forward(**_decode_inputs([cand[i]], [pos + i], [row], block_size))
             cand.append(int(greedy_sample(logits)[0]))
         target_tokens = []

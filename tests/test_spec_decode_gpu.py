@@ -58,6 +58,26 @@ def _drafts(cfg, w):
     return {"copy": (cfg, w), "perturbed": (cfg, noisy), "unrelated": (small, make_weights(small, seed=7))}
 
 
+class _Catchup:
+    """What the adapter keeps per sequence (MI355XCausalLM._forward_fused_speculation): after a step that
+    generated all k tokens, the token in front of the last one has not been through the draft."""
+
+    def __init__(self, n):
+        self.pending = [None] * n            # (position of the next step, token)
+
+    def ids(self, pos):
+        out = []
+        for i, p in enumerate(pos):
+            st, self.pending[i] = self.pending[i], None
+            out.append(st[1] if st is not None and st[0] == int(p) else -1)
+        return torch.tensor(out, dtype=torch.long)
+
+    def record(self, pos, acc, nxt, k):
+        for i, p in enumerate(pos):
+            if k >= 2 and int(nxt[i]) - int(p) == k:
+                self.pending[i] = (int(p) + k, int(acc[i, k - 2]))
+
+
 def _plain_greedy(model, prompts, blocks, n_new):
     out = [[] for _ in prompts]
     for i, p in enumerate(prompts):
@@ -80,7 +100,7 @@ def test_fused_speculation_is_lossless_and_matches_the_oracle_step(draft_kind, w
     prompts = make_prompts(cfg.vocab_size, 0)
     n_new = 24
     target = _model(cfg, w, NSEQ * K, weight_dtype)
-    draft = _model(dcfg, dw, NSEQ, weight_dtype)
+    draft = _model(dcfg, dw, 2 * NSEQ, weight_dtype)        # every sequence + one catch-up row each
     blocks_a = [[1 + i * MB + j for j in range(MB)] for i in range(NSEQ)]
     blocks_b = [[1 + (NSEQ + i) * MB + j for j in range(MB)] for i in range(NSEQ)]
     want = _plain_greedy(target, prompts, blocks_a, n_new)       # the target alone, one token per step
@@ -93,10 +113,12 @@ def test_fused_speculation_is_lossless_and_matches_the_oracle_step(draft_kind, w
         draft.forward(**inp)
     bt = torch.tensor([b + [0] * (MB - len(b)) for b in blocks_b], dtype=torch.long)
     steps, produced = 0, 0
+    cu = _Catchup(NSEQ)
     while min(len(g) for g in got) < n_new:
         last = torch.tensor([g[-1] for g in got])
         pos = torch.tensor([len(p) + len(g) - 1 for p, g in zip(prompts, got)])
-        acc, nxt = target.forward_spec(draft, last, pos, bt, K)
+        acc, nxt = target.forward_spec(draft, last, pos, bt, K, catchup_ids=cu.ids(pos))
+        cu.record(pos, acc, nxt, K)
         masked = remask(acc, nxt, pos)
         for i in range(NSEQ):
             toks = [int(t) for t in masked[i] if t != -1]
@@ -124,7 +146,7 @@ def test_fused_speculation_step_against_the_oracle():
     w = make_weights(cfg, seed=1)
     dcfg, dw = _drafts(cfg, w)["perturbed"]
     prompts = make_prompts(cfg.vocab_size, 0)
-    target, draft = _model(cfg, w, NSEQ * K), _model(dcfg, dw, NSEQ)
+    target, draft = _model(cfg, w, NSEQ * K), _model(dcfg, dw, 2 * NSEQ)
     o_target = PagedDecoderOracle(cfg, w, NB, BS, compute="bf16")
     o_draft = PagedDecoderOracle(dcfg, dw, NB, BS, compute="bf16")
     blocks = [[1 + i * MB + j for j in range(MB)] for i in range(NSEQ)]
@@ -138,11 +160,13 @@ def test_fused_speculation_step_against_the_oracle():
         seqs.append([first])
     bt = torch.tensor(blocks, dtype=torch.long)
     agree = total = 0
+    cu = _Catchup(NSEQ)
     for _ in range(8):
         last = [s[-1] for s in seqs]
         pos = [len(p) + len(s) - 1 for p, s in zip(prompts, seqs)]
         acc_o, nxt_o = fused_speculation_step(o_target, o_draft, last, pos, bt, K, BS, MAXLEN)
-        acc, nxt = target.forward_spec(draft, torch.tensor(last), torch.tensor(pos), bt, K)
+        acc, nxt = target.forward_spec(draft, torch.tensor(last), torch.tensor(pos), bt, K, catchup_ids=cu.ids(pos))
+        cu.record(pos, acc_o, nxt_o, K)        # both sides continue from the oracle's tokens
         total += NSEQ
         agree += sum(int(torch.equal(acc[i], acc_o[i]) and nxt[i] == nxt_o[i]) for i in range(NSEQ))
         m = remask(acc_o, nxt_o, torch.tensor(pos))
@@ -160,7 +184,7 @@ def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
     only inside one block)."""
     cfg = zoo_config("tinyllama_like")
     w = make_weights(cfg, seed=3)
-    target, draft = _model(cfg, w, NSEQ * K), _model(cfg, w, NSEQ)
+    target, draft = _model(cfg, w, NSEQ * K), _model(cfg, w, 2 * NSEQ)
     g = torch.Generator().manual_seed(5)
     L = 218                                                       # windows cross the block boundary 223 | 224, then run into position 255
     p = torch.randint(0, cfg.vocab_size, (L,), generator=g).tolist()
@@ -169,13 +193,17 @@ def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
     seq = [int(target.forward(**inp).argmax(dim=1)[0])]
     draft.forward(**inp)
     bt = torch.tensor(blocks, dtype=torch.long)
+    cu = _Catchup(1)
+    full_windows = 0
     while L + len(seq) - 1 < MAXLEN:                              # as long as the last token has a position to be processed at
         pos = L + len(seq) - 1
-        acc, nxt = target.forward_spec(draft, torch.tensor([seq[-1]]), torch.tensor([pos]), bt, K)
+        acc, nxt = target.forward_spec(draft, torch.tensor([seq[-1]]), torch.tensor([pos]), bt, K, catchup_ids=cu.ids([pos]))
+        cu.record([pos], acc, nxt, K)
         n = int(nxt[0]) - pos
+        full_windows += n == min(K, MAXLEN - pos)
         assert 1 <= n <= min(K, MAXLEN - pos)
         seq.extend(acc[0, :n].tolist())
-    assert L + len(seq) == MAXLEN + 1                             # the draft is a copy: full windows, the last one clipped
+    assert L + len(seq) == MAXLEN + 1 and full_windows >= 9       # the draft is a copy and is caught up: full windows, the last one clipped
     # the same text from the target alone (fresh blocks)
     blocks2 = [[20, 21, 22, 23, 24, 25, 26, 27]]
     want = _plain_greedy(target, [p], blocks2, len(seq))

@@ -78,7 +78,7 @@ _SIGS = {
     "mi_forward_chunked": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mi_forward_spec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_int32, C.c_void_p, C.c_void_p]),
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_replay_decode": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float)]),
     "mi_replay_decode_classes": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_float)]),
     "mi_kv_stats": (C.c_int, [C.c_void_p, C.POINTER(MiKvStats)]),
@@ -325,12 +325,13 @@ class NativeModel:
                                           out.data_ptr() if tokens else None))
         return out
 
-    def forward_spec(self, draft: "NativeModel", input_ids, position_ids, block_table, k: int):
-        """Fused speculation step (reference: NxDI fused speculation behind loader.py:349-355): `k`
+    def forward_spec(self, draft: "NativeModel", input_ids, position_ids, block_table, k: int, catchup_ids=None):
+        """Fused speculation step (reference: NxDI fused speculation behind loader.py:349-355): k - 1
         chained greedy steps of `draft`, one pass of this (target) model over the B * k candidates,
         greedy acceptance.  input_ids / position_ids [B]: the last token of every sequence and its
-        position; block_table [B, MB].  -> (accepted [B, k] int64, 0-padded like NxDI's
-        accepted_tokens_with_padding; next_pos [B] int64)."""
+        position; block_table [B, MB]; catchup_ids [B] (-1 = none): the token at position - 1 where
+        the draft has not seen it yet (the step before generated k tokens).  -> (accepted [B, k]
+        int64, 0-padded like NxDI's accepted_tokens_with_padding; next_pos [B] int64)."""
         def i64(t):
             return t.to(torch.int64).contiguous()
         ids, pos = i64(input_ids).reshape(-1), i64(position_ids).reshape(-1)
@@ -338,8 +339,10 @@ class NativeModel:
         bt = i64(block_table).reshape(B, -1)
         acc = torch.empty(B, k, dtype=torch.int64)
         nxt = torch.empty(B, dtype=torch.int64)
+        cu = i64(catchup_ids).reshape(-1) if catchup_ids is not None else None
         check(self.lib.mi_forward_spec(self._ctx, draft._ctx, B, k, ids.data_ptr(), pos.data_ptr(), bt.data_ptr(),
-                                       bt.shape[1], acc.data_ptr(), nxt.data_ptr()))
+                                       bt.shape[1], cu.data_ptr() if cu is not None else None, acc.data_ptr(),
+                                       nxt.data_ptr()))
         return acc, nxt
 
     def replay_decode(self, steps: int) -> float:

@@ -209,6 +209,7 @@ else:
             self.num_computed_tokens = 0
             self.num_cached_tokens = -1
             self.block_ids: list = []
+            self.published = [0, None]         # prefix-cache chain: full blocks registered, hash of the last one
             self.max_tokens = sampling_params.max_tokens if sampling_params else 1
 
         @property
@@ -456,16 +457,21 @@ else:
                     self.evictable.pop(b, None)
                 self.ref[b] += 1
 
-        def publish(self, token_ids, blocks):
-            """Register the full blocks of `token_ids` (whose KV is now written) for reuse."""
+        def publish(self, token_ids, blocks, state=None):
+            """Register the full blocks of `token_ids` (whose KV is now written) for reuse.  `state` =
+            [blocks already registered, hash of the last of them] of this request: only blocks that
+            became full since the last call are hashed (vLLM keeps the chain per request likewise)."""
             if not self.enable_caching:
                 return
-            h = None
-            for i in range(len(token_ids) // self.block_size):
+            start, h = (state[0], state[1]) if state is not None else (0, None)
+            nfull = len(token_ids) // self.block_size
+            for i in range(start, nfull):
                 h = hash((h, tuple(token_ids[i * self.block_size:(i + 1) * self.block_size])))
                 if h not in self.cached and blocks[i] not in self.hash_of:
                     self.cached[h] = blocks[i]
                     self.hash_of[blocks[i]] = h
+            if state is not None and nfull > start:
+                state[0], state[1] = nfull, h
 
         def release(self, blocks):
             for b in reversed(blocks):
@@ -604,7 +610,8 @@ else:
                 req.num_computed_tokens += n_sched
                 idx = model_runner_output.req_id_to_index.get(req_id)
                 toks = list(model_runner_output.sampled_token_ids[idx]) if idx is not None else []
-                self.block_pool.publish(req.all_token_ids[:req.num_computed_tokens], req.block_ids)
+                if req.num_computed_tokens // self.block_size > req.published[0]:    # a block became full
+                    self.block_pool.publish(req.all_token_ids[:req.num_computed_tokens], req.block_ids, req.published)
                 stopped = False
                 if toks:
                     toks, stopped = self._update_request_with_output(req, toks)

@@ -1285,10 +1285,15 @@ int mi_forward_chunked(mi_ctx* c, int32_t n_req, int32_t total, const int64_t* i
 // (output contract: accepted tokens 0-padded to the speculation length + next position ids, re-masked
 // by _remask_fused_spec_output :308-333) and the runner's slots for the speculated positions
 // (neuronx_distributed_model_runner.py:825-830; here taken from the block table, so a window may
-// cross a block boundary).  The draft runs all k steps so that its K/V covers every token the
-// target can accept; K/V written for rejected candidates is overwritten by the next call.
+// cross a block boundary).  The draft runs k - 1 steps (candidates 1 .. k - 1); when a step accepts
+// every candidate, the last one (position pos - 1 of the next call) has not been through the draft:
+// the caller names it in draft_catchup_ids and the draft's FIRST step of the next call takes it as an
+// extra row (same launch: its K/V is written before the attention of the sequence's own row reads
+// it).  A missing catch-up never changes the text, only what the draft proposes.  K/V written for
+// rejected candidates is overwritten by the next call.
 int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* input_ids, const int64_t* position_ids,
-                    const int64_t* block_table, int32_t MB, int64_t* accepted_out, int64_t* next_pos_out) {
+                    const int64_t* block_table, int32_t MB, const int64_t* draft_catchup_ids, int64_t* accepted_out,
+                    int64_t* next_pos_out) {
   MI_CHECK(t && d && t != d && t->finalized && d->finalized, "mi_forward_spec: two finalized contexts (target, draft)");
   MI_CHECK(!t->owned_group && !d->owned_group && !t->grp && !d->grp && !t->collective() && !d->collective(),
            "mi_forward_spec: tensor-parallel contexts are not supported");
@@ -1300,6 +1305,10 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
            "mi_forward_spec: target and draft must share device, block_size, num_blocks, vocab_size and max_model_len");
   MI_CHECK(B >= 1 && k >= 1 && B * k <= kt.max_num_seqs && B <= kd.max_num_seqs,
            "mi_forward_spec: B * k rows exceed the target's max_num_seqs (or B the draft's)");
+  int n_catch = 0;
+  if (draft_catchup_ids)
+    for (int b = 0; b < B; ++b) n_catch += draft_catchup_ids[b] >= 0 && position_ids[b] >= 1;
+  MI_CHECK(B + n_catch <= kd.max_num_seqs, "mi_forward_spec: catch-up rows exceed the draft's max_num_seqs (create it with 2 x B rows)");
   MI_CHECK(MB >= 1 && MB <= t->MB_cap && MB <= d->MB_cap, "bad block-table width");
   MI_HIP(hipSetDevice(kt.device_id));
   if (d->stream != t->stream) {   // one stream for both contexts: the chain below is ordered by enqueue order alone
@@ -1323,7 +1332,8 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   set_input_views(d, true);
   DecodeStage st_t, st_d;
   decode_stage_begin(t, MB, B * k, st_t);
-  decode_stage_begin(d, MB, B, st_d);
+  decode_stage_begin(d, MB, B + n_catch, st_d);
+  int catch_row = B;
   for (int b = 0; b < B; ++b) {
     const int64_t pos = position_ids[b];
     MI_CHECK(pos >= 0 && pos < kt.max_model_len, "position out of range");
@@ -1336,6 +1346,8 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
       MI_TRY(decode_stage_row(t, b * k + i, MB, i == 0 ? input_ids[b] : 0, p, i < lim ? slot_of(p) : -1, (int)p + 1, row, st_t));
     }
     MI_TRY(decode_stage_row(d, b, MB, input_ids[b], pos, slot_of(pos), (int)pos + 1, row, st_d));
+    if (draft_catchup_ids && draft_catchup_ids[b] >= 0 && pos >= 1)   // the token in front of it, not yet in the draft's K/V
+      MI_TRY(decode_stage_row(d, catch_row++, MB, draft_catchup_ids[b], pos - 1, slot_of(pos - 1), (int)pos, row, st_d));
     // the whole window must be backed by real blocks (decode_stage_row checked the live context of its last row)
     h_limit[b] = lim;
     h_pos0[b] = (int32_t)pos;
@@ -1343,13 +1355,11 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   MI_TRY(decode_stage_push(t, MB, st_t));
   MI_TRY(decode_stage_push(d, MB, st_d));
   MI_HIP(hipMemcpyAsync(d_limit, h_limit, 2 * ms * 4, hipMemcpyHostToDevice, s));   // limit + pos0 (adjacent)
-  for (int step = 0; step < k; ++step) {
-    MI_TRY(capture_or_launch_decode(d, B, MB));
-    if (step + 1 < k) {
-      MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s, d->d_sample_scratch));
-      MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
-                                 d_cand, s));
-    }
+  for (int step = 0; step + 1 < k; ++step) {
+    MI_TRY(capture_or_launch_decode(d, step == 0 ? B + n_catch : B, MB));   // the catch-up rows ride on the first step only
+    MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s, d->d_sample_scratch));
+    MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
+                               d_cand, s));
   }
   MI_TRY(capture_or_launch_decode(t, B * k, MB));
   MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s, t->d_sample_scratch));

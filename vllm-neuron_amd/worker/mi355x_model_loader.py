@@ -115,6 +115,7 @@ class MI355XCausalLM(MI355XModelBase):
     """`forward` = one call of libmi355x_vllm's mi_forward (reference loader.py:336-365)."""
 
     draft = None     # NativeModel of the draft model when fused speculation is on
+    _draft_catchup: dict = {}    # sequence id -> (position of its next step, token the draft has not seen)
 
     def _remask_fused_spec_output(self, fused, inputs):
         """The fused speculation step hands back (reference loader.py:308-333)
@@ -152,8 +153,23 @@ class MI355XCausalLM(MI355XModelBase):
             accepted = torch.zeros(B, k, dtype=torch.long)
             accepted[:, 0] = first.reshape(B)
             next_pos = inputs["full_context_lens"].reshape(B).to(torch.long)
+            for sid in seq_ids.reshape(-1).tolist():
+                self._draft_catchup.pop(int(sid), None)
         else:
-            accepted, next_pos = self.model.forward_spec(self.draft, ids[:, 0], positions[:, 0], block_table, k)
+            # the draft runs k - 1 steps: after a step that generated all k tokens, the one in front of the
+            # last has not been through the draft -- it rides on the draft's first step of this call
+            sids = [int(x) for x in seq_ids.reshape(-1).tolist()]
+            pos_l = positions[:, 0].tolist()
+            catch = []
+            for sid, p in zip(sids, pos_l):
+                st = self._draft_catchup.pop(sid, None)
+                catch.append(st[1] if st is not None and st[0] == p else -1)
+            accepted, next_pos = self.model.forward_spec(self.draft, ids[:, 0], positions[:, 0], block_table, k,
+                                                         catchup_ids=torch.tensor(catch, dtype=torch.long))
+            if k >= 2:
+                for row, (sid, p) in enumerate(zip(sids, pos_l)):
+                    if int(next_pos[row]) - p == k:
+                        self._draft_catchup[sid] = (p + k, int(accepted[row, k - 2]))
         return self._remask_fused_spec_output([accepted, next_pos.reshape(B, 1)], inputs)
 
     def forward(self, input_ids, input_block_ids, **kwargs):
@@ -326,8 +342,10 @@ class MI355XCausalLM(MI355XModelBase):
         if geo["vocab_size"] != self.hf_config.vocab_size:
             raise ValueError("fused speculation: draft and target must share the vocabulary")
         draft_skip = cfg.get("draft_model_modules_to_not_convert") or not_converted
+        self._draft_catchup = {}
         self.draft = NativeModel(
-            num_blocks=int(num_blocks), block_size=int(block_size), max_num_seqs=max_num_seqs,
+            # rows: every sequence + one catch-up row each (mi_forward_spec)
+            num_blocks=int(num_blocks), block_size=int(block_size), max_num_seqs=2 * max_num_seqs,
             max_model_len=int(max_model_len), ctx_buckets=buckets,
             weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0, quant_type=_QUANT_TYPES[qtype] if quantized else 0,
             quantize_lm_head=int(quantized and not any("lm_head" in m for m in draft_skip)),
