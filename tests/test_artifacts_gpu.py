@@ -111,8 +111,8 @@ def test_plugin_builds_and_reuses_the_artifact_directory(tmp_path):
     # second start: the checkpoint's tensors are not needed any more
     st = os.stat(ckpt / "model.safetensors")
     (ckpt / "model.safetensors").write_bytes(b"")
-    os.utime(ckpt / "model.safetensors", (st.st_atime, st.st_mtime))
-    os.truncate(ckpt / "model.safetensors", st.st_size)           # same name / size / mtime -> same hash
+    os.truncate(ckpt / "model.safetensors", st.st_size)
+    os.utime(ckpt / "model.safetensors", (st.st_atime, st.st_mtime))   # same name / size / mtime -> same hash (set LAST: truncate touches it)
     toks2, (hit2, dir2) = run(q)
     assert hit2 and dir2 == dir1 and toks2 == toks1
     # another configuration -> another directory (and the emptied checkpoint can no longer serve it)
