@@ -62,7 +62,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpool, const uint16_t* __restrict__ vpool,
     int bs, const int32_t* __restrict__ block_table, int MB, const int32_t* __restrict__ ctx_lens,
     int nh, int nkv, int G, int NS, float* __restrict__ o_part, float* __restrict__ ml_part,
-    uint16_t* __restrict__ out, float scale_log2e, unsigned int* __restrict__ tickets = nullptr) {
+    uint16_t* __restrict__ out, float scale_log2e, unsigned int* __restrict__ tickets = nullptr, int R = 1) {
+  // R > 1 (the target's pass of a speculation step): batch rows b R .. b R + R - 1 are the SAME sequence
+  // at consecutive positions (one block-table row, context lengths growing by one).  Their query heads
+  // sit side by side in the 16 MFMA columns (column = row-in-sequence * G + head, G R <= 16) and each
+  // column masks by its own row's context length: the K/V of the sequence is read once, not R times.
   constexpr int KP = HD + 8;        // LDS row pitch (elements)
   constexpr int CPR = HD / 8;       // 16-byte chunks per row
   constexpr int KS = HD / 32, DN = HD / 16;
@@ -72,10 +76,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
   uint16_t* Vs = reinterpret_cast<uint16_t*>(dsm);                       // [NW][32][KP] bf16
   float* sm_ml = reinterpret_cast<float*>(dsm + (size_t)NW * VT * 2);    // [NW][16][2]
 
-  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z * R;   // b: first batch row of the sequence
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int ctx = ctx_lens[b];
+  const int Gc = G * R;                         // live MFMA columns
+  const int cr = c / G, ch = c - cr * G;        // column c = (row of the sequence, head of the kv group)
+  int ctx = 0;                                  // the longest context of the sequence's rows bounds the tiles walked
+  for (int r = 0; r < R; ++r) ctx = max(ctx, ctx_lens[b + r]);
+  const int ctx_c = c < Gc ? ctx_lens[b + cr] : 0;   // what this lane's column may attend to
   const int nt = ceil_div(ctx, 32), tps = ceil_div(nt, NS);
   const int t_beg = split * tps, t_end = min(nt, t_beg + tps);
   uint16_t* Vw = Vs + wave * VT;
@@ -117,8 +125,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
   u32x4_t qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
-    qf[ks] = (c < G) ? *reinterpret_cast<const u32x4_t*>(q + ((size_t)b * nh + kvh * G + c) * HD + ks * 32 + g * 8)
-                     : u32x4_t{0, 0, 0, 0};
+    qf[ks] = (c < Gc) ? *reinterpret_cast<const u32x4_t*>(q + ((size_t)(b + cr) * nh + kvh * G + ch) * HD + ks * 32 + g * 8)
+                      : u32x4_t{0, 0, 0, 0};
   f32x4_t acc[DN];
 #pragma unroll
   for (int dn = 0; dn < DN; ++dn) acc[dn] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -159,12 +167,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float sv = st[u][i] * scale_log2e;
-        if (tok0 + 16 * u + 4 * g + i >= ctx) sv = -INFINITY;
+        if (tok0 + 16 * u + 4 * g + i >= ctx_c) sv = -INFINITY;
         pv[4 * u + i] = sv;
         mx = fmaxf(mx, sv);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));       // finite: a processed tile has at least one live token
+    mx = fmaxf(mx, __shfl_xor(mx, 32));       // -inf where the column has no live token in this tile (sexp2 conventions)
     const float mn = fmaxf(mrow, mx);
     const float alpha = sexp2(mrow, mn);
     float ps = 0.f;
@@ -212,8 +220,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     sm_ml[(wave * 16 + c) * 2 + 1] = lrow;
   }
   __syncthreads();
-  for (int idx = tid; idx < G * HD; idx += NW * 64) {
-    const int h = idx / HD, d = idx % HD;
+  for (int idx = tid; idx < Gc * HD; idx += NW * 64) {
+    const int h = idx / HD, d = idx % HD;       // h: MFMA column
+    const int hr = h / G, hh = h - hr * G;      // -> (row of the sequence, head)
     float M = sm_ml[h * 2];
 #pragma unroll
     for (int w = 1; w < NW; ++w) M = fmaxf(M, sm_ml[(w * 16 + h) * 2]);
@@ -225,16 +234,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
       L += f * sm_ml[(w * 16 + h) * 2 + 1];
     }
     if constexpr (FINAL) {
-      out[((size_t)b * nh + kvh * G + h) * HD + d] = f32_to_bf16(L > 0.f ? o / L : 0.f);   // empty context -> zeros
+      out[((size_t)(b + hr) * nh + kvh * G + hh) * HD + d] = f32_to_bf16(L > 0.f ? o / L : 0.f);   // empty context -> zeros
     } else if constexpr (MERGE) {
-      const size_t row = ((size_t)b * nh + kvh * G + h) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
+      const size_t row = ((size_t)(b + hr) * nh + kvh * G + hh) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
       __hip_atomic_store(&o_part[row * HD + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_store ... sc1
       if (d == 0) {
         __hip_atomic_store(&ml_part[row * 2], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ml_part[row * 2 + 1], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
-      const size_t row = ((size_t)b * nh + kvh * G + h) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
+      const size_t row = ((size_t)(b + hr) * nh + kvh * G + hh) * kAttnMaxSplits + split;   // fixed stride: a head's m/l block is one 128-byte line
       o_part[row * HD + d] = o;
       if (d == 0) {
         ml_part[row * 2] = M;
@@ -337,13 +346,13 @@ static bool attn_merge_enabled() {
 template <int HD>
 static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int bs,
                            const int32_t* bt, int MB, const int32_t* ctx, int B, int nh, int nkv,
-                           uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed) {
-  const int G = nh / nkv, NS = attn_decode_splits(B, nkv);
+                           uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int R) {
+  const int G = nh / nkv, Bs = B / R, NS = attn_decode_splits(Bs, nkv);   // Bs sequences of R batch rows each
   // in-launch merge: needs every split's work-group resident on a CU of its own (grid <= CUs) and
   // the ticket counters at zero (the model keeps them so; the per-op entry cannot know)
   int num_cu = 0;
   if (device_num_cu(&num_cu) != MI_OK) return MI_EHIP;
-  const bool merge = attn_merge_enabled() && NS > 1 && tickets_zeroed && NS * nkv * B <= num_cu && nkv * B <= kAttnTickets;
+  const bool merge = attn_merge_enabled() && R == 1 && NS > 1 && tickets_zeroed && NS * nkv * B <= num_cu && nkv * B <= kAttnTickets;
   unsigned int* tickets = reinterpret_cast<unsigned int*>(scratch);
   float* ml_part = reinterpret_cast<float*>(tickets + kAttnTickets);
   float* o_part = ml_part + (size_t)B * nh * kAttnMaxSplits * 2;
@@ -361,14 +370,14 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
     // single CU sustains only ~32 GB/s from HBM however many loads its waves keep in flight, so
     // a short grid must split the context over CUs -- the one-launch form at B x nkv = 32 took
     // 16 us per 1k tokens of context against 8 + 5 us for split + combine.)
-    hipLaunchKernelGGL((attn_decode_kernel<HD, 8, true>), dim3(1, nkv, B), dim3(512), lds8, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e, nullptr);
+    hipLaunchKernelGGL((attn_decode_kernel<HD, 8, true>), dim3(1, nkv, Bs), dim3(512), lds8, s, q,
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e, nullptr, R);
   } else if (merge) {
     hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false, true>), dim3(NS, nkv, B), dim3(256), kMergeLds, s, q,
                        kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, out, scale_log2e, tickets);
   } else {
-    hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false>), dim3(NS, nkv, B), dim3(256), lds4, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e, nullptr);
+    hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false>), dim3(NS, nkv, Bs), dim3(256), lds4, s, q,
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e, nullptr, R);
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(nh, B), dim3(HD), 0, s, o_part, ml_part, NS, nh, out);
   }
   MI_HIP(hipGetLastError());
@@ -377,12 +386,14 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
 
 int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int block_size,
                        const int32_t* block_table, int MB, const int32_t* ctx_lens, int B, int nh,
-                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed) {
+                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int rows_per_seq) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
+  MI_CHECK(rows_per_seq >= 1 && B % rows_per_seq == 0 && (nh / nkv) * rows_per_seq <= 16,
+           "attention: rows_per_seq must divide the batch and q heads per kv head x rows_per_seq must be <= 16");
   MI_CHECK(nh % nkv == 0 && nh / nkv <= 16, "attention: q heads per kv head must be 1..16");
   MI_CHECK(block_size % 16 == 0, "attention: block_size must be a multiple of 16");
-  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
-  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed);
+  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq);
+  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq);
 }
 
 // =====================================================================================

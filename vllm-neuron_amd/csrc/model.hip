@@ -226,7 +226,8 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
     } else if (decode) {
       Scope sc(c, MI_K_ATTN_DECODE);
       MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
-                                c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true));
+                                c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true,
+                                c->attn_rows_per_seq));
     } else if (segs) {
       Scope sc(c, MI_K_ATTN_PREFILL);
       for (int i = 0; i < nseg; ++i)
@@ -485,7 +486,7 @@ float bf16_bits_to_f32(uint16_t h) {
 }
 
 int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
-  const int key = (B * 65536 + MB) ^ (int)((c->class_mask & 0xff) << 24);
+  const int key = (B * 65536 + MB) ^ (int)((c->class_mask & 0xff) << 24) ^ ((c->attn_rows_per_seq - 1) << 12);
   // a caller-supplied transport runs on the host thread: never captured
   if (!c->cfg.use_graphs || c->prof.on || c->xport_allreduce) return run_layers(c, B, true, B, MB, 0, B, 0);
   auto it = c->graphs.find(key);
@@ -1361,7 +1362,12 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
     MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
                                d_cand, s));
   }
-  MI_TRY(capture_or_launch_decode(t, B * k, MB));
+  // the k rows of a sequence share the attention's MFMA columns where they fit (q heads per kv head x k <= 16)
+  static const bool shared_cols = [] { const char* v = getenv("MI355X_SPEC_SHARED_ATTN"); return !v || v[0] != '0'; }();
+  t->attn_rows_per_seq = (shared_cols && (t->nh_l / t->nkv_l) * k <= 16) ? k : 1;
+  const int rc_pass = capture_or_launch_decode(t, B * k, MB);
+  t->attn_rows_per_seq = 1;
+  MI_TRY(rc_pass);
   MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s, t->d_sample_scratch));
   MI_TRY(launch_spec_accept(B, k, t->d_tokens, d_cand, d_limit, d_pos0, d_out, d_out + ms, s));
   MI_HIP(hipMemcpyAsync(h_out, d_out, 2 * ms * 4, hipMemcpyDeviceToHost, s));   // out + next_pos (adjacent)

@@ -96,6 +96,7 @@ struct mi_ctx {
   // on-device sampling: (top_k, top_p, temperature) rows and the sampled ids
   float *d_sparams = nullptr, *h_sparams = nullptr;
   int32_t *d_tokens = nullptr, *h_tokens = nullptr;
+  int attn_rows_per_seq = 1;                        // token generation: consecutive batch rows that are ONE sequence (speculation)
   void* d_sample_scratch = nullptr;                 // partial (value, index) pairs of the split argmax
   int32_t *d_spec = nullptr, *h_spec = nullptr;   // fused speculation (mi_forward_spec): candidates, limits, outputs
   int MB_cap = 0;
