@@ -665,3 +665,59 @@ def test_scheduler_reserves_blocks_for_the_speculation_window():
     mro = SimpleNamespace(req_id_to_index={"a": 0}, sampled_token_ids=[[105, 106, 107]])
     res = s.update_from_output(out, mro)                                            # max_tokens 6: the window is trimmed
     assert res[0].new_token_ids == [105] and res[0].finished
+
+
+def test_adapter_fused_speculation_bookkeeping():
+    """MI355XCausalLM with fused speculation on, the native library replaced by a recorder: context
+    encoding runs target AND draft and returns the first token in column 0; token generation is ONE
+    forward_spec call; after a step that generated all k tokens the second-to-last of them is handed
+    to the draft's next step (draft_catchup_ids), once, and only for that sequence; sampling requests
+    are refused (reference loader.py:349-355, 308-333)."""
+    k = 3
+
+    class Native:
+        def __init__(self):
+            self.calls = []
+
+        def forward_tokens(self, ids, *a, **kw):
+            self.calls.append(("tokens", ids.shape))
+            return torch.full((ids.shape[0],), 41, dtype=torch.long)
+
+        def forward_spec(self, draft, ids, pos, bt, kk, catchup_ids=None):
+            self.calls.append(("spec", ids.tolist(), pos.tolist(), catchup_ids.tolist()))
+            acc = torch.tensor([[7, 8, 9], [5, 0, 0]])[:ids.shape[0]]             # row 0: all k accepted, row 1: one token
+            nxt = pos + torch.tensor([3, 1])[:ids.shape[0]]
+            return acc, nxt
+
+    m = loader.MI355XCausalLM(SimpleNamespace(vocab_size=512))
+    m.mi355x_config = loader.MI355XConfig(is_block_kv_layout=True, is_prefix_caching=True, chunked_prefill_config=None,
+                                          on_device_sampling_config={"dynamic": True}, enable_fused_speculation=True,
+                                          speculation_length=k)
+    m.model, m.draft, m._draft_catchup = Native(), Native(), {}
+    greedy = torch.tensor([[1.0, 1.0, 1.0]])
+    # context encoding of one prompt (sequence id 3)
+    out = m.forward(torch.tensor([[11, 12, 13, 14]]), torch.tensor([3]), position_ids=torch.arange(4)[None],
+                    slot_mapping=torch.arange(4)[None], block_tables=torch.tensor([[1, 0]]),
+                    full_context_lens=torch.tensor([[4]]), computed_context_lens=torch.tensor([[0]]),
+                    sampling_params=greedy, prefill_completion_state=None)
+    assert out.tolist() == [[41, -1, -1]]
+    assert [c[0] for c in m.model.calls] == ["tokens"] and [c[0] for c in m.draft.calls] == ["tokens"]
+    # token generation for sequences 3 and 5
+    kw = dict(slot_mapping=torch.zeros(2, k, dtype=torch.long), block_tables=torch.tensor([[1, 0], [2, 0]]),
+              full_context_lens=torch.tensor([[5], [9]]), computed_context_lens=torch.tensor([[4], [8]]),
+              sampling_params=greedy.repeat(2, 1), prefill_completion_state=None)
+    out = m.forward(torch.tensor([[41], [77]]), torch.tensor([3, 5]), position_ids=torch.tensor([[4], [8]]), **kw)
+    assert out.tolist() == [[7, 8, 9], [5, -1, -1]]
+    assert m.model.calls[-1] == ("spec", [41, 77], [4, 8], [-1, -1])
+    assert m._draft_catchup == {3: (7, 8)}                     # sequence 3 continues at position 7; the draft has not seen token 8
+    out = m.forward(torch.tensor([[9], [5]]), torch.tensor([3, 5]), position_ids=torch.tensor([[7], [9]]), **kw)
+    assert m.model.calls[-1] == ("spec", [9, 5], [7, 9], [8, -1])
+    # a catch-up that does not match the position (the request was replaced) is dropped
+    m._draft_catchup = {5: (99, 1)}
+    m.forward(torch.tensor([[9], [5]]), torch.tensor([3, 5]), position_ids=torch.tensor([[10], [10]]), **kw)
+    assert m.model.calls[-1][3] == [-1, -1]
+    with pytest.raises(NotImplementedError, match="greedy"):
+        m.forward(torch.tensor([[9]]), torch.tensor([3]), position_ids=torch.tensor([[13]]),
+                  slot_mapping=torch.zeros(1, k, dtype=torch.long), block_tables=torch.tensor([[1, 0]]),
+                  full_context_lens=torch.tensor([[14]]), computed_context_lens=torch.tensor([[13]]),
+                  sampling_params=torch.tensor([[20.0, 0.9, 0.8]]), prefill_completion_state=None)
