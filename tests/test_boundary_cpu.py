@@ -671,8 +671,8 @@ def test_adapter_fused_speculation_bookkeeping():
     """MI355XCausalLM with fused speculation on, the native library replaced by a recorder: context
     encoding runs target AND draft and returns the first token in column 0; token generation is ONE
     forward_spec call; after a step that generated all k tokens the second-to-last of them is handed
-    to the draft's next step (draft_catchup_ids), once, and only for that sequence; sampling requests
-    are refused (reference loader.py:349-355, 308-333)."""
+    to the draft's next step (draft_catchup_ids), once, and only for that sequence; a step with a request
+    that samples falls back to one token per sequence (reference loader.py:349-355, 308-333)."""
     k = 3
 
     class Native:
@@ -716,8 +716,11 @@ def test_adapter_fused_speculation_bookkeeping():
     m._draft_catchup = {5: (99, 1)}
     m.forward(torch.tensor([[9], [5]]), torch.tensor([3, 5]), position_ids=torch.tensor([[10], [10]]), **kw)
     assert m.model.calls[-1][3] == [-1, -1]
-    with pytest.raises(NotImplementedError, match="greedy"):
-        m.forward(torch.tensor([[9]]), torch.tensor([3]), position_ids=torch.tensor([[13]]),
-                  slot_mapping=torch.zeros(1, k, dtype=torch.long), block_tables=torch.tensor([[1, 0]]),
-                  full_context_lens=torch.tensor([[14]]), computed_context_lens=torch.tensor([[13]]),
-                  sampling_params=torch.tensor([[20.0, 0.9, 0.8]]), prefill_completion_state=None)
+    # a step with a request that samples: one token per sequence from the ordinary sampler, both models fed
+    n_t, n_d = len(m.model.calls), len(m.draft.calls)
+    out = m.forward(torch.tensor([[9]]), torch.tensor([3]), position_ids=torch.tensor([[13]]),
+                    slot_mapping=torch.zeros(1, k, dtype=torch.long), block_tables=torch.tensor([[1, 0]]),
+                    full_context_lens=torch.tensor([[14]]), computed_context_lens=torch.tensor([[13]]),
+                    sampling_params=torch.tensor([[20.0, 0.9, 0.8]]), prefill_completion_state=None)
+    assert out.tolist() == [[41, -1, -1]]
+    assert m.model.calls[n_t:] == [("tokens", torch.Size([1, 1]))] and m.draft.calls[n_d:] == [("tokens", torch.Size([1, 1]))]

@@ -265,11 +265,12 @@ def test_engine_with_speculative_config_generates_the_target_text(draft_kind, qu
         check_against_golden(name, outs)
     if draft_kind != "unrelated":
         assert multi > 0                     # some step generated more than one token for a request
-    # sampling requests are refused: acceptance is by greedy agreement
-    eng.add_request(prompts[0], SamplingParams(temperature=0.8, top_k=20, max_tokens=4))
-    with pytest.raises(Exception, match="greedy"):
-        while eng.has_unfinished_requests():
-            eng.step()
+    # a request that samples (the reference's EAGLE test runs top_k = 50): served one token per step
+    rid = eng.add_request(prompts[0], SamplingParams(temperature=0.8, top_k=20, max_tokens=6))
+    while eng.has_unfinished_requests():
+        _, out = eng.step()
+        assert all(len(t) <= 1 for t in out.sampled_token_ids)
+    assert len(eng.outputs[rid].token_ids) == 6 and eng.outputs[rid].finished
     runner = eng.worker.model_runner
     runner.model.draft.close()
     runner.model.model.close()

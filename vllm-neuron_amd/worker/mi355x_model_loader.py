@@ -140,12 +140,28 @@ class MI355XCausalLM(MI355XModelBase):
         cfg = self.mi355x_config
         k = int(cfg.speculation_length)
         sp = inputs.get("sampling_params")
-        if sp is not None and bool((sp[:, 0] != 1).any()):
-            raise NotImplementedError("fused speculation accepts by greedy agreement: every request must sample "
-                                      "greedily (temperature 0 / top_k 1)")
+        sampled = sp is not None and bool((sp[:, 0] != 1).any())
         positions = inputs["position_ids"]
         B = ids.shape[0]
-        if ids.shape[1] > 1:      # context encoding
+        if sampled:
+            # Acceptance here is by greedy agreement.  A step with a request that SAMPLES (top_k / top_p /
+            # temperature; the reference's EAGLE test runs top_k = 50) generates one token per sequence with
+            # the ordinary on-device sampler; the draft sees the same tokens so its K/V stays usable for the
+            # greedy steps that follow.
+            self._sample_calls += 1
+            first = self.model.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping[:, :ids.shape[1]]
+                                              if ids.shape[1] == 1 else slot_mapping,
+                                              inputs["full_context_lens"], computed, sampling_params=sp,
+                                              seed=(self._sample_seed << 32) + self._sample_calls)
+            self.draft.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping[:, :ids.shape[1]]
+                                      if ids.shape[1] == 1 else slot_mapping,
+                                      inputs["full_context_lens"], computed, sampling_params=None, seed=0)
+            accepted = torch.zeros(B, k, dtype=torch.long)
+            accepted[:, 0] = first.reshape(B)
+            next_pos = inputs["full_context_lens"].reshape(B).to(torch.long)
+            for sid in seq_ids.reshape(-1).tolist():
+                self._draft_catchup.pop(int(sid), None)
+        elif ids.shape[1] > 1:      # context encoding
             first = self.model.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping,
                                               inputs["full_context_lens"], computed, sampling_params=None, seed=0)
             self.draft.forward_tokens(ids, positions, seq_ids, block_table, slot_mapping,
