@@ -409,6 +409,24 @@ def main():
     engine_dev = engine_decode_rate()
     model_adapter.mi355x_config.on_device_sampling_config = None
 
+    # ---- the same loop under vLLM's native scheduler (chunked prefill on): every step is a
+    #      ragged record; once all prompts are encoded the library runs it as a token-generation step
+    engine_chunked = None
+    if tp == 1 and args.model == "llama31_8b":
+        oc = dict(override)
+        oc["chunked_prefill_config"] = {"max_num_seqs": MAX_NUM_SEQS}
+        engc = MI355XEngine(hf, max_model_len=MAX_MODEL_LEN, max_num_seqs=MAX_NUM_SEQS, block_size=BLOCK_SIZE,
+                            num_gpu_blocks_override=PA_NUM_BLOCKS, enable_prefix_caching=True, enable_chunked_prefill=True,
+                            max_num_batched_tokens=2048, override_mi355x_config=oc)
+        main_eng, eng = eng, engc
+        try:
+            engine_decode_rate()                      # warm-up: graph capture, allocator
+            engine_chunked = engine_decode_rate()
+        finally:
+            eng = main_eng
+        engc.worker.model_runner.model.model.close()
+        del engc
+
     # ---- decode at other context lengths (ctx 256 / 1024 / 2040), device-resident ---
     from tests.helpers import decode_inputs
     mb = MAX_MODEL_LEN // BLOCK_SIZE
@@ -521,6 +539,7 @@ def main():
                    "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
         "engine_decode_tokens_per_s": engine_cpu,
         "engine_decode_tokens_per_s_on_device_sampling": engine_dev,
+        "engine_decode_tokens_per_s_chunked_prefill_scheduler": engine_chunked,
         "ttft_p50_ms": ttft, "ttft_mode": "weight-only quantization (the parity path)",
         "ttft_p50_ms_fp8_activations": ttft_a8, "fp8_activation_first_token_agreement": agreement,
         "prefix_cache_ttft_ms": prefix_ttft,

@@ -1240,6 +1240,17 @@ int mi_forward_chunked(mi_ctx* c, int32_t n_req, int32_t total, const int64_t* i
   MI_CHECK(n_req >= 1 && n_req <= k.max_num_seqs, "more requests than max_num_seqs");
   MI_CHECK(total >= n_req && total <= c->max_rows, "token batch larger than the largest context-encoding bucket");
   MI_CHECK(MB >= 1 && MB <= c->MB_cap, "bad block-table width");
+  static const bool decode_shortcut = [] { const char* v = getenv("MI355X_CHUNKED_DECODE_SHORTCUT"); return !v || v[0] != '0'; }();
+  if (decode_shortcut && total == n_req) {
+    // every request contributes exactly one token: this IS a token-generation step (vLLM's native scheduler
+    // sends those through the same ragged record once all prompts are encoded) -- the weight-streaming
+    // kernels, the split-context attention and the step's hipGraph instead of a 1-row context encoding per request
+    bool one_each = true;
+    for (int i = 0; i < n_req; ++i) one_each = one_each && full_context_lens[i] - computed_context_lens[i] == 1;
+    if (one_each)
+      return forward_impl(c, n_req, 1, input_ids, position_ids, nullptr, block_table, MB, slot_mapping, 1, full_context_lens,
+                          computed_context_lens, logits_out, sampling_params, seed, tokens_out);
+  }
   MI_HIP(hipSetDevice(k.device_id));
   hipStream_t s = c->stream;
   const int bs = k.block_size, V = k.vocab_size;
