@@ -230,10 +230,24 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
                                 c->attn_rows_per_seq));
     } else if (segs) {
       Scope sc(c, MI_K_ATTN_PREFILL);
-      for (int i = 0; i < nseg; ++i)
+      static const bool batch_decodes = [] { const char* v = getenv("MI355X_RAGGED_DECODE_ATTN"); return !v || v[0] != '0'; }();
+      for (int i = 0; i < nseg;) {
+        int j = i;
+        while (batch_decodes && j < nseg && segs[j].n == 1) ++j;
+        if (j > i) {
+          // a run of requests that generate (one token each, consecutive rows and table rows): ONE split-context
+          // decode-attention launch for all of them instead of a one-query context encoding per request
+          MI_TRY(launch_attn_decode(c->qbuf + (size_t)segs[i].row0 * c->q_dim, kpool, vpool, k.block_size,
+                                    c->d_bt + (size_t)i * MB, MB, c->d_seg_ctx + i, j - i, c->nh_l, c->nkv_l, c->hd,
+                                    c->attn_out + (size_t)segs[i].row0 * c->q_dim, c->attn_scratch, s));
+          i = j;
+          continue;
+        }
         MI_TRY(launch_attn_prefill(c->qbuf + (size_t)segs[i].row0 * c->q_dim, segs[i].n, segs[i].pos0, kpool, vpool,
                                    k.block_size, c->d_bt + (size_t)i * MB, c->nh_l, c->nkv_l, c->hd,
                                    c->attn_out + (size_t)segs[i].row0 * c->q_dim, s));
+        ++i;
+      }
     } else {
       Scope sc(c, MI_K_ATTN_PREFILL);
       MI_TRY(launch_attn_prefill(c->qbuf, rows, q_pos0, kpool, vpool, k.block_size, c->d_bt, c->nh_l,
@@ -959,7 +973,7 @@ int mi_finalize(mi_ctx* c) {
   c->MB_cap = ceil_div(k.max_model_len, k.block_size) + 1;
   const size_t nbt = (size_t)k.max_num_seqs * c->MB_cap;
   // inputs: [block tables][context lengths][ids][positions][slots], one block on each side
-  c->inputs_elems = nbt + (size_t)k.max_num_seqs + 3 * R;
+  c->inputs_elems = nbt + (size_t)k.max_num_seqs + 3 * R + (size_t)k.max_num_seqs;   // [tables][per-request ints][ids][pos][slots][per-request context lengths]
   MI_TRY(dmalloc(&c->d_inputs, c->inputs_elems, ws));
   MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_inputs), c->inputs_elems * 4, hipHostMallocDefault));
   memset(c->h_inputs, 0, c->inputs_elems * 4);
@@ -1015,6 +1029,7 @@ static void set_input_views(mi_ctx* c, bool decode_step) {
   } else {
     c->d_bt = c->d_inputs; c->d_ctx = c->d_inputs + nbt; c->d_ids = c->d_ctx + ms; c->d_pos = c->d_ids + R; c->d_slots = c->d_pos + R;
     c->h_bt = c->h_inputs; c->h_ctx = c->h_inputs + nbt; c->h_ids = c->h_ctx + ms; c->h_pos = c->h_ids + R; c->h_slots = c->h_pos + R;
+    c->d_seg_ctx = c->d_slots + R; c->h_seg_ctx = c->h_slots + R;
   }
 }
 
@@ -1279,6 +1294,7 @@ int mi_forward_chunked(mi_ctx* c, int32_t n_req, int32_t total, const int64_t* i
     }
     segs[i] = Seg{row, n, comp};
     c->h_ctx[i] = row + n - 1;   // the request's last row: where its logits come from
+    c->h_seg_ctx[i] = full;      // keys the request attends to (the decode-attention launch of 1-token requests)
     row += n;
   }
   MI_CHECK(row == total, "chunk lengths do not add up to the token batch");

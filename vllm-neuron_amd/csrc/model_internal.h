@@ -76,6 +76,7 @@ struct mi_ctx {
   void* attn_scratch = nullptr;
   // step inputs
   int32_t *d_ids = nullptr, *d_pos = nullptr, *d_slots = nullptr, *d_bt = nullptr, *d_ctx = nullptr;
+  int32_t *d_seg_ctx = nullptr, *h_seg_ctx = nullptr;   // ragged records: context length of every request
   int32_t *h_ids = nullptr, *h_pos = nullptr, *h_slots = nullptr, *h_bt = nullptr, *h_ctx = nullptr;
   // d_* / h_* above are the CURRENT views: context encoding uses slices of one block (one H2D per
   // call: [block table row][ids][positions][slots]); token generation uses a second, small block
