@@ -6,7 +6,7 @@ generated on the device.  One model per BASELINE config that fits one GPU:
   config 2             Llama-3.1-8B   the same shapes, bf16 weights
   config 4             Qwen2.5-7B     28 layers, H 3584, 28/4 heads x 128, I 18944, V 152064, INT8 per-channel,
                                       qkv bias, prefix caching with a 512-token shared prefix (SURVEY 8d);
-                                      down_proj (K = 18944) runs the K-chunked GEMV
+                                      down_proj (K = 18944) runs the K-streamed GEMV (gemv_kstream_kernel)
   (config 5, Llama-3.3-70B at TP 8, is in tests/test_tp_group_gpu.py)
 
 all at block_size 32, max_num_seqs 4, max_model_len 2048, pa_num_blocks 4096 (+ the null block).

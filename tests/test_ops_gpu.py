@@ -68,7 +68,7 @@ def test_quantize_bit_exact(lib, wd, qt):
 @pytest.mark.parametrize("N,K", [(576, 448), (1024, 4096), (256, 14336), (3584, 18944), (272, 28672)])
 def test_qlinear(lib, wd, M, path, N, K):
     """(16, 14336), (4 / 16, 18944) and (* , 28672) on the GEMV path do not fit in LDS whole: they
-    run the K-chunked weight-streaming kernel (Qwen2.5-7B / Llama-3.3-70B down_proj shapes)."""
+    run the K-streamed weight-streaming kernel (gemv_kstream_kernel; Qwen2.5-7B / Llama-3.3-70B down_proj shapes)."""
     if K > 16384 and (path >= 2 or wd == "bf16") and M not in (4, 17):
         pytest.skip("big-K shapes: one GEMM and one bf16 case are enough")
     if path == 3 and wd == "bf16":

@@ -14,7 +14,7 @@ visibility of peer memory; DESIGN.md says so.
     on the reference call sequence;
   * BASELINE config 5: Llama-3.3-70B FP8 at TP 8 with the real per-rank shapes (80 layers, H 8192,
     8 q heads + 1 kv head, I 3584, V 16032 per rank): size-independent properties, and TP 8 against
-    TP 1 (whose down_proj, K = 28672, runs the K-chunked GEMV).
+    TP 1 (whose down_proj, K = 28672, runs the K-streamed GEMV).
 """
 
 import pytest
