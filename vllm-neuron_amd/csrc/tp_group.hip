@@ -332,7 +332,11 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
         if (p == r) continue;
         int can = 0;
         MI_HIP(hipDeviceCanAccessPeer(&can, cfg.tp_device_ids[r], cfg.tp_device_ids[p]));
-        MI_CHECK(can || g->use_rccl, "tp_device_ids: a pair of GPUs has no peer access (use tp_transport = RCCL)");
+        if (!can && !g->use_rccl) {   // no peer mapping between this pair: the hand-written exchange cannot run
+          fprintf(stderr, "[mi355x] GPUs %d and %d have no peer access: tensor-parallel exchange over RCCL instead\n",
+                  cfg.tp_device_ids[r], cfg.tp_device_ids[p]);
+          g->use_rccl = 1;
+        }
         if (can) {
           hipError_t pe = hipDeviceEnablePeerAccess(cfg.tp_device_ids[p], 0);
           if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) MI_HIP(pe);
