@@ -520,6 +520,18 @@ def main():
     if tp == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(MODELS["llama31_8b"] if args.model != "qwen25_7b" else HF, MAX_NUM_SEQS, DECODE_CTX)
 
+    # ---- context encoding against the MFMA roofline: algorithmic flops = 2 W N + 4 L nh hd N^2 / 2 ----
+    def prefill_flops(n):
+        head = HF["vocab_size"] * HF["hidden_size"]                 # lm_head: one row (the last token) only
+        body = weight_bytes_per_step(HF, 1, 1) - head
+        return 2.0 * body * n + 2.0 * head + 4.0 * HF["num_hidden_layers"] * HF["num_attention_heads"] * HF["head_dim"] * n * n / 2.0
+    ttft_frac = {"peak_PFLOPs": {"weight_only_bf16_mfma": 2.5 * tp, "fp8_activations_mx_fp8_mfma": 5.0 * tp},
+                 "weight_only": {b: round(prefill_flops(int(b) - 17) / (t_ms * 1e-3) / (2.5e15 * tp), 4) for b, t_ms in ttft.items()},
+                 "fp8_activations": ({b: round(prefill_flops(int(b) - 17) / (t_ms * 1e-3) / (5.0e15 * tp), 4) for b, t_ms in ttft_a8.items()}
+                                     if ttft_a8 else None),
+                 "note": "whole TTFT (scheduler, H2D, every kernel of the bucket, logits D2H, CPU sampler) against the dense MFMA "
+                         "peak of the dtype; prompts are bucket - 17 tokens; flops = 2 (W - lm_head) N + 2 lm_head + 4 L nh hd N^2 / 2 (SURVEY 8d counts the lm_head for every token: 7 % more)"}
+
     label = MODEL_LABEL[args.model]
     wname = {"f8e4m3": "FP8", "int8": "INT8", "bf16": "bf16"}[wd]
     line = {
@@ -542,6 +554,7 @@ def main():
         "engine_decode_tokens_per_s_chunked_prefill_scheduler": engine_chunked,
         "ttft_p50_ms": ttft, "ttft_mode": "weight-only quantization (the parity path)",
         "ttft_p50_ms_fp8_activations": ttft_a8, "fp8_activation_first_token_agreement": agreement,
+        "ttft_frac_of_mfma_peak": ttft_frac,
         "prefix_cache_ttft_ms": prefix_ttft,
         "device_ms_per_step": round(dev_ms / args.steps, 4),
         "decode_tokens_per_s_by_ctx": {**by_ctx, str(DECODE_CTX): round(value, 1)},
