@@ -101,3 +101,23 @@ def test_engine_with_chunked_prefill_matches_hf_golden(name, device_sampling):
     outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12))
     check_against_golden(name, outs)
     eng.worker.model_runner.model.model.close()
+
+
+def test_engine_with_chunked_prefill_and_tensor_parallelism(monkeypatch):
+    """vLLM's native scheduler on top of the in-process tensor-parallel group (both rank shards on
+    GPU 0): ragged records fan out to the shards, all-decode records run as token-generation steps
+    inside every shard, mixed records batch their 1-token requests into one decode-attention launch."""
+    from vllm_neuron_amd._vllm_compat import SamplingParams
+    from vllm_neuron_amd.engine import MI355XEngine
+    monkeypatch.setenv("MI355X_TP_LOOPBACK", "1")
+    name = "llama31_like"
+    cfg = zoo_config(name)
+    override = {"state_dict": make_weights(cfg, 1), "is_block_kv_layout": True,
+                "chunked_prefill_config": {"max_num_seqs": 4}}
+    eng = MI355XEngine(hf_like(name), max_model_len=256, max_num_seqs=4, block_size=32, enable_prefix_caching=False,
+                       tensor_parallel_size=2, enable_chunked_prefill=True, max_num_batched_tokens=48,
+                       override_mi355x_config=override)
+    prompts = make_prompts(cfg.vocab_size, 0)
+    outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=12))
+    check_against_golden(name, outs)
+    eng.worker.model_runner.model.model.close()
