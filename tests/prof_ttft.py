@@ -7,7 +7,7 @@ import bench
 from vllm_neuron_amd._vllm_compat import SamplingParams
 from vllm_neuron_amd.engine import MI355XEngine
 
-hf = SimpleNamespace(**bench.LLAMA31_8B)
+hf = SimpleNamespace(**bench.MODELS["llama31_8b"])
 override = {"synthetic_weights": {"seed": 1, "std": 0.02}, "context_encoding_buckets": bench.BUCKETS,
             "pa_num_blocks": bench.PA_NUM_BLOCKS, "quantized": True, "quantization_dtype": "f8e4m3",
             "quantization_type": "per_channel_symmetric", "prefill_fp8_activations": True}
