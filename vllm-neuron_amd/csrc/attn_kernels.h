@@ -23,7 +23,8 @@ size_t attn_scratch_bytes(int B, int nh, int hd);
 int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int block_size,
                        const int32_t* block_table, int MB, const int32_t* ctx_lens, int B, int nh,
                        int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed = false,
-                       int rows_per_seq = 1);
+                       int rows_per_seq = 1, int num_blocks = 0);
+// num_blocks > 0 (blocks of the pool): a wave's first K/V request does not wait for the context length (ids clamped into the pool)
 // rows_per_seq R > 1: batch rows b R .. b R + R - 1 are one sequence at consecutive positions (block_table row b R
 // serves them all); their heads share the MFMA columns and the sequence's K/V is read once
 // tickets_zeroed: the first 4 KiB of `scratch` (the merge tickets) were zeroed once by the owner and

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpool, const uint16_t* __restrict__ vpool,
     int bs, const int32_t* __restrict__ block_table, int MB, const int32_t* __restrict__ ctx_lens,
     int nh, int nkv, int G, int NS, float* __restrict__ o_part, float* __restrict__ ml_part,
-    uint16_t* __restrict__ out, float scale_log2e, unsigned int* __restrict__ tickets = nullptr, int R = 1) {
+    uint16_t* __restrict__ out, float scale_log2e, unsigned int* __restrict__ tickets = nullptr, int R = 1,
+    int num_blocks = 0) {
   // R > 1 (the target's pass of a speculation step): batch rows b R .. b R + R - 1 are the SAME sequence
   // at consecutive positions (one block-table row, context lengths growing by one).  Their query heads
   // sit side by side in the 16 MFMA columns (column = row-in-sequence * G + head, G R <= 16) and each
@@ -84,8 +85,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
   int ctx = 0;                                  // the longest context of the sequence's rows bounds the tiles walked
   for (int r = 0; r < R; ++r) ctx = max(ctx, ctx_lens[b + r]);
   const int ctx_c = c < Gc ? ctx_lens[b + cr] : 0;   // what this lane's column may attend to
-  const int nt = ceil_div(ctx, 32), tps = ceil_div(nt, NS);
-  const int t_beg = split * tps, t_end = min(nt, t_beg + tps);
+  // Tiles are dealt round-robin: wave w of split s takes tiles s NW + w, + NS NW, ...  Which tile a wave STARTS
+  // with therefore does not depend on the context length, so (num_blocks > 0) its first K/V request goes out
+  // beside the load of the context length instead of behind it (one L2 round trip less on the way to the first
+  // MFMA); what it fetched is masked by score, or never consumed when the tile lies beyond the context.
+  const int nt = ceil_div(ctx, 32), stride = NS * NW;
+  const int t_first = split * NW + wave, t_end = nt;
   uint16_t* Vw = Vs + wave * VT;
 
   u32x4_t kA[2 * KS], vA[NV], kB[2 * KS], vB[NV];
@@ -120,7 +125,31 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
       vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vpool + src));
     }
   };
-  issue(kA, vA, t_beg + wave);
+  if (num_blocks > 0) {
+    // speculative form of issue(): no use of the context length; table index and block id clamped into range
+    const int tok0 = t_first * 32;
+    size_t rowh[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bi = min((tok0 + 16 * u) / bs, MB - 1);
+      const int blk = min(max(block_table[(size_t)b * MB + bi], 0), num_blocks - 1);
+      rowh[u] = ((size_t)blk * nkv + kvh) * bs + ((tok0 + 16 * u) % bs);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t kbase = (rowh[u] + c) * HD + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        kA[u * KS + ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kpool + kbase + ks * 32));
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = (lane + 64 * i) / CPR, chn = (lane + 64 * i) % CPR;
+      vA[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vpool + (rowh[row >> 4] + (row & 15)) * HD + chn * 8));
+    }
+  } else {
+    issue(kA, vA, t_first);
+  }
 
   u32x4_t qf[KS];
 #pragma unroll
@@ -201,11 +230,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     }
   };
 
-  for (int tt = t_beg + wave; tt < t_end; tt += 2 * NW) {
-    issue(kB, vB, tt + NW);
+  for (int tt = t_first; tt < t_end; tt += 2 * stride) {
+    issue(kB, vB, tt + stride);
     update(kA, vA, tt);
-    issue(kA, vA, tt + 2 * NW);
-    if (tt + NW < t_end) update(kB, vB, tt + NW);
+    issue(kA, vA, tt + 2 * stride);
+    if (tt + stride < t_end) update(kB, vB, tt + stride);
   }
 
   // ---- merge the waves: O^T / m / l of wave w go to its own (now idle) LDS tile --------------
@@ -346,7 +375,7 @@ static bool attn_merge_enabled() {
 template <int HD>
 static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int bs,
                            const int32_t* bt, int MB, const int32_t* ctx, int B, int nh, int nkv,
-                           uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int R) {
+                           uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int R, int num_blocks) {
   const int G = nh / nkv, Bs = B / R, NS = attn_decode_splits(Bs, nkv);   // Bs sequences of R batch rows each
   // in-launch merge: needs every split's work-group resident on a CU of its own (grid <= CUs) and
   // the ticket counters at zero (the model keeps them so; the per-op entry cannot know)
@@ -371,13 +400,13 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
     // a short grid must split the context over CUs -- the one-launch form at B x nkv = 32 took
     // 16 us per 1k tokens of context against 8 + 5 us for split + combine.)
     hipLaunchKernelGGL((attn_decode_kernel<HD, 8, true>), dim3(1, nkv, Bs), dim3(512), lds8, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e, nullptr, R);
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, 1, nullptr, nullptr, out, scale_log2e, nullptr, R, num_blocks);
   } else if (merge) {
     hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false, true>), dim3(NS, nkv, B), dim3(256), kMergeLds, s, q,
                        kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, out, scale_log2e, tickets);
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<HD, 4, false>), dim3(NS, nkv, Bs), dim3(256), lds4, s, q,
-                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e, nullptr, R);
+                       kpool, vpool, bs, bt, MB, ctx, nh, nkv, G, NS, o_part, ml_part, nullptr, scale_log2e, nullptr, R, num_blocks);
     hipLaunchKernelGGL((attn_combine_kernel<HD>), dim3(nh, B), dim3(HD), 0, s, o_part, ml_part, NS, nh, out);
   }
   MI_HIP(hipGetLastError());
@@ -386,14 +415,15 @@ static int launch_decode_t(const uint16_t* q, const uint16_t* kpool, const uint1
 
 int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t* vpool, int block_size,
                        const int32_t* block_table, int MB, const int32_t* ctx_lens, int B, int nh,
-                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int rows_per_seq) {
+                       int nkv, int hd, uint16_t* out, void* scratch, hipStream_t s, bool tickets_zeroed, int rows_per_seq,
+                       int num_blocks) {
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
   MI_CHECK(rows_per_seq >= 1 && B % rows_per_seq == 0 && (nh / nkv) * rows_per_seq <= 16,
            "attention: rows_per_seq must divide the batch and q heads per kv head x rows_per_seq must be <= 16");
   MI_CHECK(nh % nkv == 0 && nh / nkv <= 16, "attention: q heads per kv head must be 1..16");
   MI_CHECK(block_size % 16 == 0, "attention: block_size must be a multiple of 16");
-  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq);
-  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq);
+  if (hd == 128) return launch_decode_t<128>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq, num_blocks);
+  return launch_decode_t<64>(q, kpool, vpool, block_size, block_table, MB, ctx_lens, B, nh, nkv, out, scratch, s, tickets_zeroed, rows_per_seq, num_blocks);
 }
 
 // =====================================================================================

@@ -192,6 +192,10 @@ int all_reduce_partial(mi_ctx* c, int rows) {
 // cross the chip once for all requests); attention runs per request; the logits are those of
 // each request's last row (gathered through d_ctx, which holds the last-row indices).
 struct Seg { int row0, n, pos0; };
+static bool attn_early_kv() {   // MI355X_ATTN_EARLY_KV=0: the first K/V request of the decode attention waits for the context length
+  static const bool on = [] { const char* v = getenv("MI355X_ATTN_EARLY_KV"); return !v || v[0] != '0'; }();
+  return on;
+}
 
 int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int logits_rows,
                int logits_row0, const Seg* segs = nullptr, int nseg = 0) {
@@ -227,7 +231,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       Scope sc(c, MI_K_ATTN_DECODE);
       MI_TRY(launch_attn_decode(c->qbuf, kpool, vpool, k.block_size, c->d_bt, MB, c->d_ctx, B, c->nh_l,
                                 c->nkv_l, c->hd, c->attn_out, c->attn_scratch, s, /*tickets_zeroed=*/true,
-                                c->attn_rows_per_seq));
+                                c->attn_rows_per_seq, attn_early_kv() ? k.num_blocks : 0));
     } else if (segs) {
       Scope sc(c, MI_K_ATTN_PREFILL);
       static const bool batch_decodes = [] { const char* v = getenv("MI355X_RAGGED_DECODE_ATTN"); return !v || v[0] != '0'; }();
@@ -239,7 +243,8 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
           // decode-attention launch for all of them instead of a one-query context encoding per request
           MI_TRY(launch_attn_decode(c->qbuf + (size_t)segs[i].row0 * c->q_dim, kpool, vpool, k.block_size,
                                     c->d_bt + (size_t)i * MB, MB, c->d_seg_ctx + i, j - i, c->nh_l, c->nkv_l, c->hd,
-                                    c->attn_out + (size_t)segs[i].row0 * c->q_dim, c->attn_scratch, s));
+                                    c->attn_out + (size_t)segs[i].row0 * c->q_dim, c->attn_scratch, s, false, 1,
+                                    attn_early_kv() ? k.num_blocks : 0));
           i = j;
           continue;
         }
