@@ -57,15 +57,18 @@ struct LinearW {
 int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e,
                 hipStream_t s);
 // M > 16 context-encoding path (MFMA-bound).  x is always bf16 [T, K].
+// defer != null: a K-split residual projection (EPI_RESID) leaves its slabs unsummed and describes them in *defer
+// (slab == null: nothing deferred); the caller hands them to the next row norm or to launch_splitk_flush
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e,
-                hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+                hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0, SlabSum* defer = nullptr);
+int launch_splitk_flush(const SlabSum& sl, const float* resid_in, float* out, int ld_out, hipStream_t s);
 // the wide-N LDS-DMA variant of launch_gemm (1-byte weights); launch_gemm picks it by size
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s);
 // M > 16 with FP8 activations: x8 = K-step-major e4m3 image [K / 128][ldx >= T rows][128 B] as
 // launch_rowquant_fp8 writes it (per-token scale in EpiArgs::row_scale), FP8 weights,
 // MX-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate.
 int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e,
-                   hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0);
+                   hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0, SlabSum* defer = nullptr);
 bool gemm_a8_supported(const LinearW& w);
 // bf16 rows -> K-step-major e4m3 image [K / 128][T][128 B] + per-row scale (amax / 448; all-zero row -> 1)
 int launch_rowquant_fp8(const uint16_t* x, int T, int K, int ldx, uint8_t* x8, float* row_scale, hipStream_t s);

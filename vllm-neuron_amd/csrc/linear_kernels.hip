@@ -1511,7 +1511,7 @@ static int gemm_pick_splitk(int tiles, int nks, int T, int N, size_t ws_bytes) {
 
 template <int WD>
 static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
-                          float* splitk_ws, size_t splitk_ws_bytes) {
+                          float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
   const int mtiles = ceil_div(T, kBM), ntiles = ceil_div(w.N, kBN);
   const int KS = gemm_pick_splitk(mtiles * ntiles, w.K / kBK, T, w.N, splitk_ws ? splitk_ws_bytes : 0);
@@ -1523,7 +1523,8 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
       hipLaunchKernelGGL((gemm_kernel<WD, EPI_, false>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e, nullptr); \
     } else { \
       hipLaunchKernelGGL((gemm_kernel<WD, EPI_, true>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x, ldx, e, splitk_ws); \
-      hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+      if (defer && EPI_ == EPI_RESID) { *defer = SlabSum{splitk_ws, KS, T, w.N, e.scale, e.bias, e.row_scale}; } \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
     } \
   } while (0)
   if (epi == EPI_QKV) MI_G(EPI_QKV);
@@ -1707,15 +1708,16 @@ int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int ep
 }
 
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
-                float* splitk_ws, size_t splitk_ws_bytes) {
+                float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer) {
+  if (defer) *defer = SlabSum();
   MI_CHECK(T >= 1, "gemm: T must be >= 1");
   if (gemm_wide_wanted(w, T, false) && ldx % 8 == 0) return launch_gemm_wide(w, T, x, ldx, epi, e, s);
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemm: N % 16 == 0 and K % 64 == 0 required");
   MI_CHECK(ldx % 8 == 0, "gemm: x row stride must be a multiple of 8 elements");
   switch (w.wd) {
-    case MI_W_BF16: return launch_gemm_wd<MI_W_BF16>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
-    case MI_W_F8E4M3: return launch_gemm_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
-    case MI_W_INT8: return launch_gemm_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes);
+    case MI_W_BF16: return launch_gemm_wd<MI_W_BF16>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer);
+    case MI_W_F8E4M3: return launch_gemm_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer);
+    case MI_W_INT8: return launch_gemm_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer);
   }
   set_error("gemm: bad weight dtype");
   return MI_EINVAL;
@@ -1869,12 +1871,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   epilogue<EPI>(e, m, n0, v);
 }
 
+// sum a deferred K-split (SlabSum) the plain way: splitk_reduce + residual epilogue
+int launch_splitk_flush(const SlabSum& sl, const float* resid_in, float* out, int ld_out, hipStream_t s) {
+  EpiArgs e{};
+  e.scale = sl.scale; e.bias = sl.bias; e.row_scale = sl.row_scale;
+  e.out_f32 = out; e.resid_in = resid_in; e.ld_out = ld_out;
+  hipLaunchKernelGGL((splitk_reduce_kernel<EPI_RESID>), dim3(ceil_div(sl.T * (sl.N / 4), 256)), dim3(256), 0, s, sl.slab, sl.KS,
+                     sl.T, sl.N, e);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 bool gemm_a8_supported(const LinearW& w) {
   return w.wd == MI_W_F8E4M3 && w.K % kA8BK == 0 && w.N % 16 == 0;
 }
 
 int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi, const EpiArgs& e, hipStream_t s,
-                   float* splitk_ws, size_t splitk_ws_bytes) {
+                   float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer) {
+  if (defer) *defer = SlabSum();
   MI_CHECK(T >= 1, "gemm_a8: T must be >= 1");
   MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
   MI_CHECK(ldx >= T && e.row_scale != nullptr, "gemm_a8: x8 is the K-step-major image of >= T rows, with its row scales");
@@ -1899,7 +1913,8 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
       hipLaunchKernelGGL((gemm_a8_kernel<EPI_, false, ntw>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, nullptr); \
     } else { \
       hipLaunchKernelGGL((gemm_a8_kernel<EPI_, true, ntw>), grid, dim3(256), 0, s, W, NT, KT, T, w.K, x8, ldx, e, splitk_ws); \
-      hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+      if (defer && EPI_ == EPI_RESID) { *defer = SlabSum{splitk_ws, KS, T, w.N, e.scale, e.bias, e.row_scale}; } \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
     } \
   } while (0)
   if (epi == EPI_QKV) MI_A8(EPI_QKV);

@@ -173,6 +173,16 @@ __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (a + b -
 // ---- per-device launch state ------------------------------------------------------------
 // One process may drive several GPUs (the in-process tensor-parallel group): kernel attributes
 // and the CU count belong to the CURRENT device, never to the process.
+// A K-split GEMM whose slabs have not been summed yet: y[m, n] = (sum_z slab[z][m][n]) * scale[n] (* row_scale[m]) + bias[n]
+// (the arithmetic of splitk_reduce_kernel + epilogue, in that order).  Consumed by the row-norm kernel that reads the
+// residual stream next (one launch and one round trip of the residual less), or flushed by launch_splitk_flush.
+struct SlabSum {
+  const float* slab = nullptr;      // [KS][T][N] raw fp32 accumulators
+  int KS = 0, T = 0, N = 0;
+  const float* scale = nullptr;     // [N]
+  const float* bias = nullptr;      // [N] or null
+  const float* row_scale = nullptr; // [T] or null (FP8 activations)
+};
 int device_num_cu(int* out);                                  // CUs of the current device
 int ensure_dynamic_lds(const void* kernel, int bytes);        // hipFuncSetAttribute once per (device, kernel)
 

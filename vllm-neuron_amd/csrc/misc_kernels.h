@@ -3,12 +3,15 @@
 
 namespace mi {
 int launch_embed(const int32_t* ids, const uint16_t* table, int T, int H, float* resid, hipStream_t s);
+// slabs: the K-split sum of the projection that produced this residual add, not summed yet (SlabSum): the row is
+// resid_in + (sum of slabs) * scale + bias, written to resid_out and normalised -- same arithmetic, same order as
+// splitk_reduce + residual epilogue followed by this kernel
 int launch_norm_rows(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
-                     int H, float eps, uint16_t* y, hipStream_t s);
+                     int H, float eps, uint16_t* y, hipStream_t s, const SlabSum* slabs = nullptr);
 // the same row, emitted as the FP8 GEMM's input: bf16-rounded, then e4m3 with scale amax / 448,
 // K-step-major image [H / 128][T][128 B] + row_scale[T]
 int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
-                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s);
+                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s, const SlabSum* slabs = nullptr);
 // dst[i, :] = src[rows[i], :]   (fp32 rows of H elements, H % 4 == 0)
 // ---- fused speculation (model.hip, mi_forward_spec) ----
 // After draft step `step` (0-based): the draft's sampled tokens become (a) candidate step + 1 of every

@@ -75,16 +75,32 @@ template <bool FP8>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ resid_in, const float* __restrict__ partial,
                                                         float* __restrict__ resid_out, const float* __restrict__ gain,
                                                         int H, float eps, uint16_t* __restrict__ y,
-                                                        uint8_t* __restrict__ x8, float* __restrict__ row_scale) {
+                                                        uint8_t* __restrict__ x8, float* __restrict__ row_scale, SlabSum sl) {
   extern __shared__ __attribute__((aligned(16))) float hrow[];  // H floats + 8
   const int t = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)t * H;
   float ss = 0.f;
+  const float sl_rs = (sl.slab && sl.row_scale) ? sl.row_scale[t] : 1.f;   // read before this launch may overwrite it (FP8: same array)
   for (int c4 = tid; c4 < H / 4; c4 += 256) {
     float4 a = *reinterpret_cast<const float4*>(resid_in + o + c4 * 4);
     if (partial) {
       const float4 p = *reinterpret_cast<const float4*>(partial + o + c4 * 4);
       a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    if (sl.slab) {   // the residual add of a K-split projection: slabs in slice order, scale, bias, + residual
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int z = 0; z < sl.KS; ++z) {
+        const float4 q = *reinterpret_cast<const float4*>(sl.slab + ((size_t)z * sl.T + t) * sl.N + c4 * 4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      float4 sc = *reinterpret_cast<const float4*>(sl.scale + c4 * 4);
+      if (sl.row_scale) { sc.x *= sl_rs; sc.y *= sl_rs; sc.z *= sl_rs; sc.w *= sl_rs; }
+      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+      if (sl.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(sl.bias + c4 * 4);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     if (resid_out) *reinterpret_cast<float4*>(resid_out + o + c4 * 4) = a;
     *reinterpret_cast<float4*>(hrow + c4 * 4) = a;
@@ -129,18 +145,20 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
   }
 }
 int launch_norm_rows(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
-                     int H, float eps, uint16_t* y, hipStream_t s) {
+                     int H, float eps, uint16_t* y, hipStream_t s, const SlabSum* slabs) {
   MI_CHECK(H % 4 == 0 && H <= 32768, "rmsnorm: H % 4 == 0 and H <= 32768 required");
+  MI_CHECK(!slabs || (slabs->T == T && slabs->N == H && resid_out), "rmsnorm: pending K-split sum of another shape");
   hipLaunchKernelGGL(norm_rows_kernel<false>, dim3(T), dim3(256), (H + 8) * sizeof(float), s, resid_in, partial, resid_out,
-                     gain, H, eps, y, nullptr, nullptr);
+                     gain, H, eps, y, nullptr, nullptr, slabs ? *slabs : SlabSum());
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
 int launch_norm_rows_fp8(const float* resid_in, const float* partial, float* resid_out, const float* gain, int T,
-                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s) {
+                         int H, float eps, uint8_t* x8, float* row_scale, hipStream_t s, const SlabSum* slabs) {
   MI_CHECK(H % 128 == 0 && H <= 32768, "rmsnorm + fp8: H % 128 == 0 and H <= 32768 required");
+  MI_CHECK(!slabs || (slabs->T == T && slabs->N == H && resid_out), "rmsnorm: pending K-split sum of another shape");
   hipLaunchKernelGGL(norm_rows_kernel<true>, dim3(T), dim3(256), (H + 8) * sizeof(float), s, resid_in, partial, resid_out,
-                     gain, H, eps, nullptr, x8, row_scale);
+                     gain, H, eps, nullptr, x8, row_scale, slabs ? *slabs : SlabSum());
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -107,6 +107,15 @@ int prof_collect(mi_ctx* c) {
 // ---- linear dispatch --------------------------------------------------------------------
 // rows x K activations -> epilogue.  Token-generation sized inputs stream the weights
 // (GEMV); larger ones go through rmsnorm rows + MFMA GEMM.
+// a deferred K-split sum (SlabSum) that no row norm took over: sum it the plain way
+int flush_pending(mi_ctx* c) {
+  if (!c->pend.slab) return MI_OK;
+  Scope sc(c, MI_K_GEMM);
+  const SlabSum sl = c->pend;
+  c->pend = SlabSum();
+  return launch_splitk_flush(sl, c->pend_in, c->pend_out, sl.N, c->stream);
+}
+
 int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi, EpiArgs e) {
   e.scale = L.scale;
   e.bias = L.bias;
@@ -121,14 +130,35 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   const bool a8 = c->cfg.prefill_fp8_activations && gemm_a8_supported(L.view());
   if (pro == PRO_NORM) {
     Scope sc(c, MI_K_OTHER);
+    // A K-split residual projection in front of this norm left its slabs unsummed: the norm sums them on the way
+    // (sum, scale, bias, + residual: the arithmetic of splitk_reduce + epilogue) and writes the residual stream.
+    const SlabSum* slabs = nullptr;
+    const float* rin = p.resid_in;
+    float* rout = p.resid_out;
+    if (c->pend.slab) {
+      if (p.resid_in == c->pend_out && !p.partial && !p.resid_out && rows == c->pend.T && L.K == c->pend.N) {
+        slabs = &c->pend;
+        rin = c->pend_in;
+        rout = c->pend_out;
+      } else {
+        MI_TRY(flush_pending(c));
+      }
+    }
     if (a8) {   // norm and per-token quantization in one pass over the row
-      MI_TRY(launch_norm_rows_fp8(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->x8, c->x8_scale, c->stream));
+      MI_TRY(launch_norm_rows_fp8(rin, p.partial, rout, p.gain, rows, L.K, p.eps, c->x8, c->x8_scale, c->stream, slabs));
     } else {
-      MI_TRY(launch_norm_rows(p.resid_in, p.partial, p.resid_out, p.gain, rows, L.K, p.eps, c->xn, c->stream));
+      MI_TRY(launch_norm_rows(rin, p.partial, rout, p.gain, rows, L.K, p.eps, c->xn, c->stream, slabs));
       x = c->xn;
       ldx = L.K;
     }
+    c->pend = SlabSum();
   }
+  // a residual projection whose K-split sum the next norm can take over (one work-group per row there)
+  static const bool fuse = [] { const char* v = getenv("MI355X_FUSE_SPLITK_NORM"); return !v || v[0] != '0'; }();
+  SlabSum* defer = (fuse && epi == EPI_RESID && !c->pend.slab) ? &c->pend : nullptr;
+  auto note_deferred = [&]() {
+    if (defer && c->pend.slab) { c->pend_in = e.resid_in; c->pend_out = e.out_f32; }
+  };
   if (a8) {
     if (pro != PRO_NORM) {
       Scope sc(c, MI_K_OTHER);
@@ -136,10 +166,14 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
     }
     e.row_scale = c->x8_scale;
     Scope sc(c, MI_K_GEMM);
-    return launch_gemm_a8(L.view(), rows, c->x8, rows, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
+    MI_TRY(launch_gemm_a8(L.view(), rows, c->x8, rows, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes, defer));
+    note_deferred();
+    return MI_OK;
   }
   Scope sc(c, MI_K_GEMM);
-  return launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes);
+  MI_TRY(launch_gemm(L.view(), rows, x, ldx, epi, e, c->stream, c->splitk_ws, c->splitk_ws_bytes, defer));
+  note_deferred();
+  return MI_OK;
 }
 
 // Host-side stage timing of the token-generation call (MI355X_HOST_TIMING=1: printed at destroy).
@@ -201,6 +235,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
                int logits_row0, const Seg* segs = nullptr, int nseg = 0) {
   const mi_model_config& k = c->cfg;
   hipStream_t s = c->stream;
+  c->pend = SlabSum();   // (a call that failed half way may have left one behind)
   if (c->runs(MI_K_OTHER)) {
     Scope sc(c, MI_K_OTHER);
     MI_TRY(launch_embed(c->d_ids, c->embed, rows, c->H, c->resid[0], s));
@@ -303,6 +338,7 @@ int run_layers(mi_ctx* c, int rows, bool decode, int B, int MB, int q_pos0, int 
       }
     }
   }
+  MI_TRY(flush_pending(c));   // the last down projection's K-split sum: the final norm reads other rows (or a gather of rows)
   {  // final norm + lm_head on the rows that are sampled (loader.py:363: logits[:, -1, :])
     ProArgs p{};
     p.resid_in = c->resid[cur] + (size_t)logits_row0 * c->H;

@@ -70,6 +70,9 @@ struct mi_ctx {
   uint8_t* x8 = nullptr;        // FP8-activation GEMM input [rows, K]
   float* x8_scale = nullptr;    // its per-token scales [rows]
   float* splitk_ws = nullptr;   // fp32 K-split slabs of short-prompt GEMMs
+  mi::SlabSum pend;               // a residual projection's K-split sum left for the next row norm (run_linear)
+  const float* pend_in = nullptr; // ... the residual it adds to
+  float* pend_out = nullptr;      // ... and where residual + projection goes
   size_t splitk_ws_bytes = 0;
   float* logits = nullptr;      // [max_num_seqs, V_l]
   float* logits_all = nullptr;  // [tp, max_num_seqs, V_l] (tp > 1)
