@@ -155,9 +155,9 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   }
   // a residual projection whose K-split sum the next norm can take over (one work-group per row there)
   static const bool fuse = [] { const char* v = getenv("MI355X_FUSE_SPLITK_NORM"); return !v || v[0] != '0'; }();
-  // (from 512 rows on: the norm runs one work-group per row -- with few rows the K-split sum is the wider kernel on its
+  // (from 384 rows on -- the 512 bucket holds 495: the norm runs one work-group per row -- with few rows the K-split sum is the wider kernel on its
   //  own; measured at 32 rows: 14.2 us fused against 5.0 + 4.6 us)
-  SlabSum* defer = (fuse && epi == EPI_RESID && rows >= 512 && !c->pend.slab) ? &c->pend : nullptr;
+  SlabSum* defer = (fuse && epi == EPI_RESID && rows >= 384 && !c->pend.slab) ? &c->pend : nullptr;
   auto note_deferred = [&]() {
     if (defer && c->pend.slab) { c->pend_in = e.resid_in; c->pend_out = e.out_f32; }
   };
