@@ -181,7 +181,8 @@ int mi_forward_chunked(mi_ctx* ctx, int32_t n_req, int32_t total, const int64_t*
  * and the draft's first step takes it as an extra row.  Leaving it out never changes the output,
  * only the quality of the draft's proposals.  Needs
  * target max_num_seqs >= B * k, draft max_num_seqs >= B + catch-up rows (2 B), and both contexts created with the same
- * device, block_size, num_blocks, vocab_size and max_model_len; TP = 1.  From the first call on the
+ * device (the target's rank 0 GPU when the target is an in-process tensor-parallel group; the draft is never
+ * sharded), block_size, num_blocks, vocab_size and max_model_len.  From the first call on the
  * draft context runs on the target's stream: destroy the draft before the target. */
 int mi_forward_spec(mi_ctx* target, mi_ctx* draft, int32_t B, int32_t k, const int64_t* input_ids,
                     const int64_t* position_ids, const int64_t* block_table, int32_t MB,

@@ -274,3 +274,35 @@ def test_engine_with_speculative_config_generates_the_target_text(draft_kind, qu
     runner = eng.worker.model_runner
     runner.model.draft.close()
     runner.model.model.close()
+
+
+def test_engine_speculation_with_a_tensor_parallel_target(monkeypatch):
+    """The reference's own speculation test runs tensor-parallel (test/tiny/test_eagle_speculative_decoding.py:
+    tensor_parallel_size=32).  Here: the target as an in-process group of 2 rank shards (both on GPU 0), the
+    draft unsharded on rank 0's GPU; candidates' ids are handed to every shard, the vocabulary-parallel logits
+    meet at rank 0's sampler.  Same greedy text as the plain engine."""
+    from tests.test_engine_gpu import check_against_golden
+    from vllm_neuron_amd._vllm_compat import SamplingParams, SimpleModelConfig, SimpleSpeculativeConfig
+    from vllm_neuron_amd.engine import MI355XEngine
+    monkeypatch.setenv("MI355X_TP_LOOPBACK", "1")
+    name = "llama31_like"
+    cfg = zoo_config(name)
+    w = make_weights(cfg, seed=1)
+    dcfg, dw = _drafts(cfg, w)["perturbed"]
+    prompts = make_prompts(cfg.vocab_size, 0)
+    spec = SimpleSpeculativeConfig(num_speculative_tokens=K, draft_model_config=SimpleModelConfig(model="", hf_config=_hf_like(dcfg)))
+    eng = MI355XEngine(_hf_like(cfg), max_model_len=256, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                       tensor_parallel_size=2, speculative_config=spec,
+                       override_mi355x_config={"state_dict": w, "draft_state_dict": dw})
+    multi = 0
+    for p in prompts:
+        eng.add_request(p, SamplingParams(temperature=0.0, max_tokens=12))
+    while eng.has_unfinished_requests():
+        _, out = eng.step()
+        multi += sum(len(t) > 1 for t in out.sampled_token_ids)
+    outs = [eng.outputs[f"req-{i}"] for i in range(len(prompts))]
+    check_against_golden(name, outs)
+    assert multi > 0
+    runner = eng.worker.model_runner
+    runner.model.draft.close()
+    runner.model.model.close()

@@ -1366,89 +1366,156 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
                     const int64_t* block_table, int32_t MB, const int64_t* draft_catchup_ids, int64_t* accepted_out,
                     int64_t* next_pos_out) {
   MI_CHECK(t && d && t != d && t->finalized && d->finalized, "mi_forward_spec: two finalized contexts (target, draft)");
-  MI_CHECK(!t->owned_group && !d->owned_group && !t->grp && !d->grp && !t->collective() && !d->collective(),
-           "mi_forward_spec: tensor-parallel contexts are not supported");
+  MI_CHECK(!d->owned_group && !d->grp && !d->collective() && !t->grp && (t->owned_group || !t->collective()),
+           "mi_forward_spec: the draft is a single-GPU context; the target a single-GPU context or an in-process tensor-parallel group");
   MI_CHECK(input_ids && position_ids && block_table && accepted_out && next_pos_out, "null argument");
-  const mi_model_config& kt = t->cfg;
+  // the target's rank shards (one: the context itself).  Everything the step keeps on the device besides the
+  // shards' own inputs lives with shard 0, on whose GPU (and stream) the draft runs.
+  mi_group* g = t->owned_group;
+  std::vector<mi_ctx*> ranks = g ? g->ranks : std::vector<mi_ctx*>{t};
+  mi_ctx* t0 = ranks[0];
+  const mi_model_config& kt = t0->cfg;
   const mi_model_config& kd = d->cfg;
   MI_CHECK(kt.device_id == kd.device_id && kt.block_size == kd.block_size && kt.num_blocks == kd.num_blocks &&
            kt.vocab_size == kd.vocab_size && kt.max_model_len == kd.max_model_len,
-           "mi_forward_spec: target and draft must share device, block_size, num_blocks, vocab_size and max_model_len");
+           "mi_forward_spec: target (rank 0) and draft must share device, block_size, num_blocks, vocab_size and max_model_len");
   MI_CHECK(B >= 1 && k >= 1 && B * k <= kt.max_num_seqs && B <= kd.max_num_seqs,
            "mi_forward_spec: B * k rows exceed the target's max_num_seqs (or B the draft's)");
   int n_catch = 0;
   if (draft_catchup_ids)
     for (int b = 0; b < B; ++b) n_catch += draft_catchup_ids[b] >= 0 && position_ids[b] >= 1;
   MI_CHECK(B + n_catch <= kd.max_num_seqs, "mi_forward_spec: catch-up rows exceed the draft's max_num_seqs (create it with 2 x B rows)");
-  MI_CHECK(MB >= 1 && MB <= t->MB_cap && MB <= d->MB_cap, "bad block-table width");
-  MI_HIP(hipSetDevice(kt.device_id));
-  if (d->stream != t->stream) {   // one stream for both contexts: the chain below is ordered by enqueue order alone
-    MI_HIP(hipStreamSynchronize(d->stream));
-    if (d->stream_owned) hipStreamDestroy(d->stream);
-    d->stream = t->stream;
-    d->stream_owned = false;
-  }
-  hipStream_t s = t->stream;
-  const size_t ms = (size_t)kt.max_num_seqs;
-  if (!t->d_spec) {   // [cand][limit][pos0][out][next_pos], max_num_seqs ints each
-    MI_HIP(hipMalloc(&t->d_spec, 5 * ms * 4));
-    MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t->h_spec), 5 * ms * 4, hipHostMallocDefault));
-    memset(t->h_spec, 0, 5 * ms * 4);
-  }
-  int32_t *d_cand = t->d_spec, *d_limit = t->d_spec + ms, *d_pos0 = t->d_spec + 2 * ms, *d_out = t->d_spec + 3 * ms;
-  int32_t *h_limit = t->h_spec + ms, *h_pos0 = t->h_spec + 2 * ms, *h_out = t->h_spec + 3 * ms;
-  const int bs = kt.block_size;
-
-  set_input_views(t, true);
-  set_input_views(d, true);
-  DecodeStage st_t, st_d;
-  decode_stage_begin(t, MB, B * k, st_t);
-  decode_stage_begin(d, MB, B + n_catch, st_d);
-  int catch_row = B;
+  MI_CHECK(MB >= 1 && MB <= t0->MB_cap && MB <= d->MB_cap, "bad block-table width");
   for (int b = 0; b < B; ++b) {
     const int64_t pos = position_ids[b];
     MI_CHECK(pos >= 0 && pos < kt.max_model_len, "position out of range");
-    const int lim = (int)std::min<int64_t>(k, kt.max_model_len - pos);   // candidate rows that fit the model length
-    const int64_t* row = block_table + (size_t)b * MB;
-    MI_CHECK(ceil_div((int)pos + lim, bs) <= MB, "block_table narrower than the speculation window");
-    auto slot_of = [&](int64_t p) { return row[p / bs] * bs + p % bs; };
-    for (int i = 0; i < k; ++i) {
-      const int64_t p = pos + std::min(i, lim - 1);
-      MI_TRY(decode_stage_row(t, b * k + i, MB, i == 0 ? input_ids[b] : 0, p, i < lim ? slot_of(p) : -1, (int)p + 1, row, st_t));
-    }
-    MI_TRY(decode_stage_row(d, b, MB, input_ids[b], pos, slot_of(pos), (int)pos + 1, row, st_d));
-    if (draft_catchup_ids && draft_catchup_ids[b] >= 0 && pos >= 1)   // the token in front of it, not yet in the draft's K/V
-      MI_TRY(decode_stage_row(d, catch_row++, MB, draft_catchup_ids[b], pos - 1, slot_of(pos - 1), (int)pos, row, st_d));
-    // the whole window must be backed by real blocks (decode_stage_row checked the live context of its last row)
-    h_limit[b] = lim;
-    h_pos0[b] = (int32_t)pos;
+    MI_CHECK(ceil_div((int)pos + (int)std::min<int64_t>(k, kt.max_model_len - pos), kt.block_size) <= MB,
+             "block_table narrower than the speculation window");
   }
-  MI_TRY(decode_stage_push(t, MB, st_t));
-  MI_TRY(decode_stage_push(d, MB, st_d));
-  MI_HIP(hipMemcpyAsync(d_limit, h_limit, 2 * ms * 4, hipMemcpyHostToDevice, s));   // limit + pos0 (adjacent)
-  for (int step = 0; step + 1 < k; ++step) {
-    MI_TRY(capture_or_launch_decode(d, step == 0 ? B + n_catch : B, MB));   // the catch-up rows ride on the first step only
-    MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s, d->d_sample_scratch));
-    MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t->d_ids,
-                               d_cand, s));
-  }
-  // the k rows of a sequence share the attention's MFMA columns where they fit (q heads per kv head x k <= 16)
+  const size_t ms = (size_t)kt.max_num_seqs;
+  const int bs = kt.block_size;
+  auto lim_of = [&](int b) { return (int)std::min<int64_t>(k, kt.max_model_len - position_ids[b]); };   // candidate rows that fit the model length
+  auto slot_of = [&](int b, int64_t p) { return block_table[(size_t)b * MB + p / bs] * bs + p % bs; };
   static const bool shared_cols = [] { const char* v = getenv("MI355X_SPEC_SHARED_ATTN"); return !v || v[0] != '0'; }();
-  t->attn_rows_per_seq = (shared_cols && (t->nh_l / t->nkv_l) * k <= 16) ? k : 1;
-  const int rc_pass = capture_or_launch_decode(t, B * k, MB);
-  t->attn_rows_per_seq = 1;
-  MI_TRY(rc_pass);
-  MI_TRY(launch_sample_rows(t->logits, 1, kt.max_num_seqs, t->V_l, B * k, nullptr, 0, 0, t->d_tokens, s, t->d_sample_scratch));
-  MI_TRY(launch_spec_accept(B, k, t->d_tokens, d_cand, d_limit, d_pos0, d_out, d_out + ms, s));
-  MI_HIP(hipMemcpyAsync(h_out, d_out, 2 * ms * 4, hipMemcpyDeviceToHost, s));   // out + next_pos (adjacent)
-  MI_HIP(hipStreamSynchronize(s));
-  for (int i = 0; i < B * k; ++i) accepted_out[i] = h_out[i];
-  for (int b = 0; b < B; ++b) next_pos_out[b] = h_out[ms + b];
-  t->last_B = B * k;
-  t->last_MB = MB;
-  d->last_B = B;
-  d->last_MB = MB;
-  return MI_OK;
+  // the k rows of a sequence share the attention's MFMA columns where they fit (q heads per kv head x k <= 16)
+  const int rows_per_seq = (shared_cols && (t0->nh_l / t0->nkv_l) * k <= 16) ? k : 1;
+
+  // every shard: its copy of the B * k candidate rows (ids of candidates 1.. arrive on the device)
+  auto stage_target = [&](mi_ctx* rc) -> int {
+    set_input_views(rc, true);
+    DecodeStage st;
+    decode_stage_begin(rc, MB, B * k, st);
+    for (int b = 0; b < B; ++b) {
+      const int64_t pos = position_ids[b];
+      const int lim = lim_of(b);
+      for (int i = 0; i < k; ++i) {
+        const int64_t p = pos + std::min(i, lim - 1);
+        MI_TRY(decode_stage_row(rc, b * k + i, MB, i == 0 ? input_ids[b] : 0, p, i < lim ? slot_of(b, p) : -1, (int)p + 1,
+                                block_table + (size_t)b * MB, st));
+      }
+    }
+    return decode_stage_push(rc, MB, st);
+  };
+  // shard 0: the draft's k - 1 chained steps; candidate i + 1 lands in shard 0's input ids and in `cand`
+  auto draft_chain = [&]() -> int {
+    MI_HIP(hipSetDevice(kt.device_id));
+    if (d->stream != t0->stream) {   // one stream for the draft and shard 0: the chain is ordered by enqueue order alone
+      MI_HIP(hipStreamSynchronize(d->stream));
+      if (d->stream_owned) hipStreamDestroy(d->stream);
+      d->stream = t0->stream;
+      d->stream_owned = false;
+    }
+    hipStream_t s = t0->stream;
+    if (!t0->d_spec) {   // [cand][limit][pos0][out][next_pos], max_num_seqs ints each
+      MI_HIP(hipMalloc(&t0->d_spec, 5 * ms * 4));
+      MI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t0->h_spec), 5 * ms * 4, hipHostMallocDefault));
+      memset(t0->h_spec, 0, 5 * ms * 4);
+    }
+    int32_t *d_cand = t0->d_spec, *d_limit = t0->d_spec + ms;
+    int32_t *h_limit = t0->h_spec + ms, *h_pos0 = t0->h_spec + 2 * ms;
+    set_input_views(d, true);
+    DecodeStage st_d;
+    decode_stage_begin(d, MB, B + n_catch, st_d);
+    int catch_row = B;
+    for (int b = 0; b < B; ++b) {
+      const int64_t pos = position_ids[b];
+      const int64_t* row = block_table + (size_t)b * MB;
+      MI_TRY(decode_stage_row(d, b, MB, input_ids[b], pos, slot_of(b, pos), (int)pos + 1, row, st_d));
+      if (draft_catchup_ids && draft_catchup_ids[b] >= 0 && pos >= 1)   // the token in front of it, not yet in the draft's K/V
+        MI_TRY(decode_stage_row(d, catch_row++, MB, draft_catchup_ids[b], pos - 1, slot_of(b, pos - 1), (int)pos, row, st_d));
+      h_limit[b] = lim_of(b);
+      h_pos0[b] = (int32_t)pos;
+    }
+    MI_TRY(decode_stage_push(d, MB, st_d));
+    MI_HIP(hipMemcpyAsync(d_limit, h_limit, 2 * ms * 4, hipMemcpyHostToDevice, s));   // limit + pos0 (adjacent)
+    for (int step = 0; step + 1 < k; ++step) {
+      MI_TRY(capture_or_launch_decode(d, step == 0 ? B + n_catch : B, MB));   // the catch-up rows ride on the first step only
+      MI_TRY(launch_sample_rows(d->logits, 1, kd.max_num_seqs, d->V_l, B, nullptr, 0, 0, d->d_tokens, s, d->d_sample_scratch));
+      MI_TRY(launch_spec_advance(B, k, step, d->d_tokens, d->d_dec, kd.max_num_seqs, d->d_dec_bt, MB, bs, d_limit, t0->d_ids,
+                                 d_cand, s));
+    }
+    d->last_B = B;
+    d->last_MB = MB;
+    return MI_OK;
+  };
+  auto target_pass = [&](mi_ctx* rc) -> int {
+    rc->attn_rows_per_seq = rows_per_seq;
+    const int rc_pass = capture_or_launch_decode(rc, B * k, MB);
+    rc->attn_rows_per_seq = 1;
+    rc->last_B = B * k;
+    rc->last_MB = MB;
+    return rc_pass;
+  };
+  auto accept = [&]() -> int {   // shard 0: its d_tokens hold the target's greedy choice of every row
+    hipStream_t s = t0->stream;
+    int32_t *d_cand = t0->d_spec, *d_limit = t0->d_spec + ms, *d_pos0 = t0->d_spec + 2 * ms, *d_out = t0->d_spec + 3 * ms;
+    int32_t* h_out = t0->h_spec + 3 * ms;
+    MI_TRY(launch_spec_accept(B, k, t0->d_tokens, d_cand, d_limit, d_pos0, d_out, d_out + ms, s));
+    MI_HIP(hipMemcpyAsync(h_out, d_out, 2 * ms * 4, hipMemcpyDeviceToHost, s));   // out + next_pos (adjacent)
+    MI_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < B * k; ++i) accepted_out[i] = h_out[i];
+    for (int b = 0; b < B; ++b) next_pos_out[b] = h_out[ms + b];
+    return MI_OK;
+  };
+
+  if (!g) {
+    MI_HIP(hipSetDevice(kt.device_id));
+    MI_TRY(stage_target(t0));
+    MI_TRY(draft_chain());
+    MI_TRY(target_pass(t0));
+    MI_TRY(launch_sample_rows(t0->logits, 1, kt.max_num_seqs, t0->V_l, B * k, nullptr, 0, 0, t0->d_tokens, t0->stream,
+                              t0->d_sample_scratch));
+    return accept();
+  }
+  // ---- tensor-parallel target: the same phases, every shard on its own thread ----
+  hipEvent_t ids_ready = nullptr;
+  if (!g->lockstep) MI_HIP(hipEventCreateWithFlags(&ids_ready, hipEventDisableTiming));
+  int rc = group_run(g, [&](mi_ctx* rcx, int r) -> int {
+    MI_TRY(stage_target(rcx));
+    if (r != 0) return MI_OK;
+    MI_TRY(draft_chain());
+    if (ids_ready) MI_HIP(hipEventRecord(ids_ready, t0->stream));
+    return MI_OK;
+  });
+  if (rc == MI_OK)
+    rc = group_run(g, [&](mi_ctx* rcx, int r) -> int {
+      if (r != 0) {   // the candidates' ids: from shard 0's inputs into this shard's (one stream and GPU in loopback mode)
+        if (ids_ready) {
+          MI_HIP(hipStreamWaitEvent(rcx->stream, ids_ready, 0));
+          MI_HIP(hipMemcpyPeerAsync(rcx->d_ids, rcx->cfg.device_id, t0->d_ids, kt.device_id, (size_t)B * k * 4, rcx->stream));
+        } else {
+          MI_HIP(hipMemcpyAsync(rcx->d_ids, t0->d_ids, (size_t)B * k * 4, hipMemcpyDeviceToDevice, rcx->stream));
+        }
+      }
+      return target_pass(rcx);
+    });
+  std::vector<int64_t> greedy((size_t)B * k);
+  if (rc == MI_OK)   // vocabulary-parallel logits -> shard 0's sampler (the on-device sampling path of the group)
+    rc = group_run(g, [&](mi_ctx* rcx, int) -> int { return sample_on_device(rcx, B * k, 0, nullptr, 0, greedy.data()); });
+  if (ids_ready) hipEventDestroy(ids_ready);
+  MI_TRY(rc);
+  MI_HIP(hipSetDevice(kt.device_id));
+  return accept();
 }
 
 int mi_replay_decode(mi_ctx* c, int32_t steps, float* elapsed_ms) {

@@ -296,9 +296,9 @@ class MI355XCausalLM(MI355XModelBase):
         fused_spec = bool(cfg.get("enable_fused_speculation"))
         spec_len = int(cfg.get("speculation_length") or 0) if fused_spec else 0
         if fused_spec:
-            if spec_len < 1 or speculative_config is None or chunked or tp_degree > 1 or not cfg["is_block_kv_layout"]:
+            if spec_len < 1 or speculative_config is None or chunked or not cfg["is_block_kv_layout"]:
                 raise NotImplementedError("fused speculation needs num_speculative_tokens >= 1, a draft model, the block "
-                                          "KV layout (prefix caching on), tensor_parallel_size 1 and no chunked prefill")
+                                          "KV layout (prefix caching on) and no chunked prefill")
         self.model = NativeModel(
             num_blocks=int(num_blocks), block_size=int(block_size),
             # the target scores every sequence's speculation window in one token-generation pass
@@ -365,7 +365,9 @@ class MI355XCausalLM(MI355XModelBase):
             max_model_len=int(max_model_len), ctx_buckets=buckets,
             weight_dtype=_QUANT_DTYPES[qdtype] if quantized else 0, quant_type=_QUANT_TYPES[qtype] if quantized else 0,
             quantize_lm_head=int(quantized and not any("lm_head" in m for m in draft_skip)),
-            tp_degree=1, tp_rank=0, device_id=int(kwargs.get("device_id", 0)), use_graphs=int(cfg.get("use_graphs", 1)),
+            # the draft is not sharded: it runs on the GPU of the target's rank 0
+            tp_degree=1, tp_rank=0, device_id=int((kwargs.get("tp_device_ids") or [kwargs.get("device_id", 0)])[0]),
+            use_graphs=int(cfg.get("use_graphs", 1)),
             prefill_fp8_activations=int(bool(cfg.get("prefill_fp8_activations", False))), **geo)
         synthetic, state_dict = cfg.get("draft_synthetic_weights"), cfg.get("draft_state_dict")
         if synthetic is not None:
