@@ -250,3 +250,64 @@ def test_qwen25_7b_tp8_padded_heads_against_tp1():
         cos = torch.nn.functional.cosine_similarity(a[key].float(), b[key].float()).min().item()
         print(f"Qwen2.5-7B TP8 vs TP1 [{key}]: rms/std {rms:.4f} max/std {mx:.3f} cos {cos:.4f}")
         assert rms <= 0.06 and mx <= 0.35 and cos > 0.995, (key, rms, mx, cos)
+
+
+def test_llama33_70b_tp8_fused_speculation():
+    """Config 5's shapes under speculation: the 16-row pass of every rank shard (H = 8192: the norm-prologue
+    projections stage 16 x 8192 activations in K-chunks), candidates' ids handed to 8 shards, vocabulary-parallel
+    sampling of 16 rows.  8 of the 80 layers (the kernels and shapes are per layer); the draft is a small
+    unrelated model, so nearly every step yields one token -- what is checked is that the text is the target's
+    own greedy text (ids may part only at a near-tie of the plain run, as in the 8B test)."""
+    from vllm_neuron_amd._native import MI_Q, MI_TP_ALL_RANKS, MI_W, NativeModel
+    K = 4
+    geo = dict(LLAMA33_70B, num_layers=8)
+    common = dict(num_blocks=F_NB, block_size=F_BS, max_model_len=F_MAXLEN, weight_dtype=MI_W["f8e4m3"],
+                  quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1, device_id=0, use_graphs=1,
+                  ctx_buckets=[256, 512, 1024, 2048], prefill_fp8_activations=0)
+    target = NativeModel(**geo, max_num_seqs=F_NSEQ * K, tp_degree=8, tp_rank=MI_TP_ALL_RANKS, tp_device_ids=[0] * 8, **common)
+    target.init_synthetic_weights(1, 0.02)
+    target.finalize()
+    dgeo = dict(LLAMA33_70B, num_layers=2, hidden_size=1024, num_heads=8, num_kv_heads=2, intermediate_size=2048)
+    draft = NativeModel(**dgeo, max_num_seqs=2 * F_NSEQ, tp_degree=1, tp_rank=0, **common)
+    draft.init_synthetic_weights(3, 0.02)
+    draft.finalize()
+    g = torch.Generator().manual_seed(12)
+    nseq, n_new = 2, 6
+    prompts = [torch.randint(0, 128256, (150 + 9 * i,), generator=g).tolist() for i in range(nseq)]
+    blocks = (torch.randperm(F_NB - 1, generator=g) + 1).tolist()
+    rows_a = [blocks[i * F_MB:(i + 1) * F_MB] for i in range(nseq)]
+    rows_b = [blocks[(nseq + i) * F_MB:(nseq + i + 1) * F_MB] for i in range(nseq)]
+    want, gaps = [[] for _ in prompts], [[] for _ in prompts]
+
+    def take(i, row):
+        top2 = row.topk(2)
+        want[i].append(int(top2.indices[0]))
+        gaps[i].append(float(top2.values[0] - top2.values[1]))
+    for i, p in enumerate(prompts):
+        take(i, target.forward(**prefill_inputs(p, rows_a[i], F_BS, F_MAXLEN, 0))[0])
+    for s in range(1, n_new):
+        lg = target.forward(**decode_inputs([w[-1] for w in want], [len(p) + s - 1 for p in prompts], rows_a, F_BS, F_MAXLEN))
+        for i in range(nseq):
+            take(i, lg[i])
+    got = [[] for _ in prompts]
+    for i, p in enumerate(prompts):
+        inp = prefill_inputs(p, rows_b[i], F_BS, F_MAXLEN, 0)
+        got[i].append(int(target.forward(**inp).argmax(dim=1)[0]))
+        draft.forward(**inp)
+    bt = torch.tensor(rows_b, dtype=torch.long)
+    while min(len(x) for x in got) < n_new:
+        last = torch.tensor([x[-1] for x in got])
+        pos = torch.tensor([len(p) + len(x) - 1 for p, x in zip(prompts, got)])
+        acc, nxt = target.forward_spec(draft, last, pos, bt, K)
+        for i in range(nseq):
+            n = int(nxt[i]) - int(pos[i])
+            assert 1 <= n <= K
+            got[i].extend(acc[i, :n].tolist())
+    std = 1.0
+    for i in range(nseq):
+        for s, (a, b) in enumerate(zip(got[i][:n_new], want[i])):
+            if a != b:
+                assert gaps[i][s] < 0.25 * std, (i, s, a, b, gaps[i][s])
+                break
+    draft.close()
+    target.close()
