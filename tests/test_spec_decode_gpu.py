@@ -306,3 +306,35 @@ def test_engine_speculation_with_a_tensor_parallel_target(monkeypatch):
     runner = eng.worker.model_runner
     runner.model.draft.close()
     runner.model.model.close()
+
+
+def test_forward_spec_argument_checks():
+    """Bad calls come back as errors with a message (MI_EINVAL -> ValueError), never as a fault on the GPU."""
+    cfg = zoo_config("tinyllama_like")
+    w = make_weights(cfg, seed=3)
+    target, draft = _model(cfg, w, NSEQ * K), _model(cfg, w, 2 * NSEQ)
+    small = _model(cfg, w, 2)                                      # too few rows for 4 x 4 candidates
+    bt = torch.tensor([[1, 2, 3, 4, 5, 6, 7, 8]] * NSEQ, dtype=torch.long)
+    ids, pos = torch.tensor([1, 2, 3, 4]), torch.tensor([10, 11, 12, 13])
+    with pytest.raises(ValueError, match="max_num_seqs"):
+        small.forward_spec(draft, ids, pos, bt, K)
+    with pytest.raises(ValueError, match="two finalized contexts"):
+        target.forward_spec(target, ids, pos, bt, K)
+    with pytest.raises(ValueError, match="position out of range"):
+        target.forward_spec(draft, ids, torch.tensor([10, 11, 12, MAXLEN]), bt, K)
+    with pytest.raises(ValueError, match="narrower than the speculation window"):
+        target.forward_spec(draft, ids, torch.tensor([10, 11, 12, 63]), bt[:, :2], K)   # positions 63..66 need 3 blocks
+    with pytest.raises(ValueError, match="token id out of range"):
+        target.forward_spec(draft, torch.tensor([1, 2, 3, cfg.vocab_size]), pos, bt, K)
+    with pytest.raises(ValueError, match="block_table entry out of range"):
+        bad = bt.clone()
+        bad[2, 0] = NB + 5
+        target.forward_spec(draft, ids, pos, bad, K)
+    with pytest.raises(ValueError, match="catch-up rows"):
+        tiny_draft = _model(cfg, w, NSEQ)
+        target.forward_spec(tiny_draft, ids, pos, bt, K, catchup_ids=torch.tensor([5, 5, 5, 5]))
+    # and a good call still works afterwards
+    acc, nxt = target.forward_spec(draft, ids, pos, bt, K)
+    assert acc.shape == (NSEQ, K) and bool(((nxt - pos) >= 1).all())
+    for m in (small, draft, target):
+        m.close()
