@@ -193,6 +193,32 @@ def test_forward_rejects_bad_inputs():
     model.close()
 
 
+def test_failed_token_generation_call_does_not_poison_the_resident_block_tables():
+    """The block tables of token generation live on the device; the host keeps a shadow of what it sent.  A call
+    whose SECOND row is bad has already compared (and recorded) the first row when it fails, without sending it:
+    the next good call must send that row again.  Two identical models, one of them fed the bad call first."""
+    cfg = zoo_config("tinyllama_like")
+    w = make_weights(cfg, 1)
+    prompts = make_prompts(cfg.vocab_size, 0)[:2]
+    blocks = [[1 + i * MB + j for j in range(MB)] for i in range(2)]
+    outs = []
+    for poison in (True, False):
+        model = native_model(cfg, w, "bf16")
+        last = []
+        for i, p in enumerate(prompts):
+            last.append(int(model.forward(**prefill_inputs(p, blocks[i], BS, MAXLEN, 0)).argmax(dim=1)[0]))
+        good = decode_inputs(last, [len(p) for p in prompts], blocks, BS, MAXLEN)
+        if poison:
+            bad = dict(good)
+            bad["block_table"] = good["block_table"].clone()
+            bad["block_table"][1, 0] = NB + 7                     # row 0 is fine and is recorded before row 1 fails
+            with pytest.raises(ValueError, match="block_table entry out of range"):
+                model.forward(**bad)
+        outs.append(model.forward(**good))
+        model.close()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_collective_path_single_rank_equals_fused_path():
     """The tensor-parallel code path (fp32 partial -> RCCL all-reduce -> partial folded in by the
     next norm prologue, vocab all-gather) with a ONE-rank communicator must give bit-identical

@@ -1080,6 +1080,14 @@ static void set_input_views(mi_ctx* c, bool decode_step) {
 // (block tables are resident on the device; a row is re-sent only when it differs from the host
 //  shadow of what the device holds, and only entries that became live are range-checked)
 struct DecodeStage { int row_lo = 0, row_hi = -1; };
+// A staging pass that fails half way (a bad row behind good ones) has already recorded the good rows in the host
+// shadow without sending them: forget the shadow, the next call re-sends every row.
+struct ShadowGuard {
+  mi_ctx* c;
+  bool pushed = false;
+  explicit ShadowGuard(mi_ctx* c_) : c(c_) {}
+  ~ShadowGuard() { if (!pushed) c->bt_shadow_MB = -1; }
+};
 static void decode_stage_begin(mi_ctx* c, int MB, int B, DecodeStage& st) {
   const mi_model_config& k = c->cfg;
   if (c->bt_shadow_MB != MB) {   // another table width: nothing on the device can be reused
@@ -1212,6 +1220,7 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
     g_ht.start();
     use_inputs(true);
     DecodeStage st;
+    ShadowGuard guard(c);
     decode_stage_begin(c, MB, B, st);
     for (int b = 0; b < B; ++b)
       MI_TRY(decode_stage_row(c, b, MB, input_ids[b], position_ids[b], slot_mapping[(size_t)b * SM], (int)full_context_lens[b],
@@ -1219,6 +1228,7 @@ static int forward_impl(mi_ctx* c, int32_t B, int32_t S, const int64_t* input_id
     auto push_inputs = [&]() -> int { return decode_stage_push(c, MB, st); };
     g_ht.lap(0);
     MI_TRY(push_inputs());
+    guard.pushed = true;
     g_ht.lap(1);
     MI_TRY(capture_or_launch_decode(c, B, MB));
     g_ht.lap(2);
@@ -1404,6 +1414,7 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   auto stage_target = [&](mi_ctx* rc) -> int {
     set_input_views(rc, true);
     DecodeStage st;
+    ShadowGuard guard(rc);
     decode_stage_begin(rc, MB, B * k, st);
     for (int b = 0; b < B; ++b) {
       const int64_t pos = position_ids[b];
@@ -1414,7 +1425,9 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
                                 block_table + (size_t)b * MB, st));
       }
     }
-    return decode_stage_push(rc, MB, st);
+    MI_TRY(decode_stage_push(rc, MB, st));
+    guard.pushed = true;
+    return MI_OK;
   };
   // shard 0: the draft's k - 1 chained steps; candidate i + 1 lands in shard 0's input ids and in `cand`
   auto draft_chain = [&]() -> int {
@@ -1435,6 +1448,7 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
     int32_t *h_limit = t0->h_spec + ms, *h_pos0 = t0->h_spec + 2 * ms;
     set_input_views(d, true);
     DecodeStage st_d;
+    ShadowGuard guard_d(d);
     decode_stage_begin(d, MB, B + n_catch, st_d);
     int catch_row = B;
     for (int b = 0; b < B; ++b) {
@@ -1447,6 +1461,7 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
       h_pos0[b] = (int32_t)pos;
     }
     MI_TRY(decode_stage_push(d, MB, st_d));
+    guard_d.pushed = true;
     MI_HIP(hipMemcpyAsync(d_limit, h_limit, 2 * ms * 4, hipMemcpyHostToDevice, s));   // limit + pos0 (adjacent)
     for (int step = 0; step + 1 < k; ++step) {
       MI_TRY(capture_or_launch_decode(d, step == 0 ? B + n_catch : B, MB));   // the catch-up rows ride on the first step only
