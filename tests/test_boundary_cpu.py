@@ -724,3 +724,16 @@ def test_adapter_fused_speculation_bookkeeping():
                     sampling_params=torch.tensor([[20.0, 0.9, 0.8]]), prefill_completion_state=None)
     assert out.tolist() == [[41, -1, -1]]
     assert m.model.calls[n_t:] == [("tokens", torch.Size([1, 1]))] and m.draft.calls[n_d:] == [("tokens", torch.Size([1, 1]))]
+
+
+def test_check_stop_no_condition_and_pooling_params():          # reference test_scheduler.py:598-660
+    r = req(0, max_tokens=20)
+    for t in (1, 3, 4, 5):
+        r.append_output_token_ids(t)
+    assert check_stop_with_min_tokens(r, 100) is False and not r.is_finished()
+    # pooling requests stop when (and only when) a pooler output arrives
+    r = req(1, max_tokens=100)
+    r.pooling_params = object()
+    assert check_stop_with_min_tokens(r, 100, pooler_output=None) is False and not r.is_finished()
+    assert check_stop_with_min_tokens(r, 100, pooler_output=torch.tensor([1.0])) is True
+    assert r.status == RequestStatus.FINISHED_STOPPED
