@@ -737,3 +737,68 @@ def test_check_stop_no_condition_and_pooling_params():          # reference test
     assert check_stop_with_min_tokens(r, 100, pooler_output=None) is False and not r.is_finished()
     assert check_stop_with_min_tokens(r, 100, pooler_output=torch.tensor([1.0])) is True
     assert r.status == RequestStatus.FINISHED_STOPPED
+
+
+def test_model_config_overrides_with_a_stand_in_vllm(monkeypatch):   # reference test_platform.py:251-530, 552-650
+    """vLLM is not installed here; a stand-in `vllm.config.ModelConfig` receives the overrides the
+    platform installs at registration and they are exercised the way the reference's tests do:
+    head-count divisibility no longer checked, external launcher needs a seed, expert parallelism
+    delegates, pipeline parallelism checks the model and switches async output off, quantization /
+    cuda-graph verification are no-ops, the user's max_model_len is trusted, applying twice is harmless."""
+    import sys
+    import types
+
+    class ModelConfig:
+        def verify_with_parallel_config(self, parallel_config):
+            raise AssertionError("upstream verifier: head count must divide the TP degree")
+
+        def _verify_quantization(self):
+            raise AssertionError("upstream quantization verifier")
+
+        def _verify_cuda_graph(self):
+            raise AssertionError("upstream cuda-graph verifier")
+
+        def get_and_verify_max_len(self, max_model_len):
+            raise AssertionError("upstream max_model_len verifier")
+    vllm = types.ModuleType("vllm")
+    vllm_config = types.ModuleType("vllm.config")
+    vllm_config.ModelConfig = ModelConfig
+    vllm.config = vllm_config
+    monkeypatch.setitem(sys.modules, "vllm", vllm)
+    monkeypatch.setitem(sys.modules, "vllm.config", vllm_config)
+    monkeypatch.setattr(plat.MI355XPlatform, "_config_overrides_applied", False)
+    plat.MI355XPlatform.pre_register_and_update(parser=object())
+    assert plat.MI355XPlatform._config_overrides_applied
+    plat.MI355XPlatform.pre_register_and_update(None)              # second call: nothing to do
+
+    mc = ModelConfig()
+    mc.seed, mc.spec_target_max_model_len, mc.use_async_output_proc = 0, None, True
+    pc = SimpleNamespace(distributed_executor_backend="uni", enable_expert_parallel=False, pipeline_parallel_size=1)
+    mc.verify_with_parallel_config(pc)                             # 28 heads at TP 8 would pass: nothing is checked
+    mc._verify_quantization()
+    mc._verify_cuda_graph()
+    assert mc.get_and_verify_max_len(4096) == 4096
+    mc.spec_target_max_model_len = 1024
+    assert mc.get_and_verify_max_len(4096) == 1024
+    # external launcher: the seed must be set
+    pc.distributed_executor_backend = "external_launcher"
+    mc.seed = None
+    with pytest.raises(AssertionError, match="Seed must be set"):
+        mc.verify_with_parallel_config(pc)
+    mc.seed = 1
+    mc.verify_with_parallel_config(pc)
+    # expert parallelism delegates to the upstream check
+    calls = []
+    mc._verify_with_expert_parallelism = lambda: calls.append("ep")
+    pc.enable_expert_parallel = True
+    mc.verify_with_parallel_config(pc)
+    assert calls == ["ep"]
+    # pipeline parallelism: model support is required; async output processing is switched off
+    pc.enable_expert_parallel, pc.pipeline_parallel_size = False, 2
+    mc.architectures = ["LlamaForCausalLM"]
+    mc.registry = SimpleNamespace(is_pp_supported_model=lambda archs: False)
+    with pytest.raises(NotImplementedError, match="Pipeline parallelism is not supported"):
+        mc.verify_with_parallel_config(pc)
+    mc.registry = SimpleNamespace(is_pp_supported_model=lambda archs: True)
+    mc.verify_with_parallel_config(pc)
+    assert mc.use_async_output_proc is False
