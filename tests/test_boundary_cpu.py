@@ -4,6 +4,7 @@ known-answer tables are the ones the reference's own unit tests pin
 (/root/reference/test/unit/: test_init.py, test_platform.py, core/test_scheduler.py,
 worker/test_model_loader.py, worker/test_model_runner.py — cited per test)."""
 
+import os
 import warnings
 from types import SimpleNamespace
 
@@ -802,3 +803,47 @@ def test_model_config_overrides_with_a_stand_in_vllm(monkeypatch):   # reference
     mc.registry = SimpleNamespace(is_pp_supported_model=lambda archs: True)
     mc.verify_with_parallel_config(pc)
     assert mc.use_async_output_proc is False
+
+
+def test_model_base_and_sample_contract():                      # reference test_model_loader.py: base-class NotImplemented, sample()
+    base = loader.MI355XModelBase(SimpleNamespace())
+    for call in (lambda: base.forward(None, None, None, None), lambda: base.sample(torch.zeros(1, 4)),
+                 lambda: base.load_weights("", "LlamaForCausalLM")):
+        with pytest.raises(NotImplementedError):
+            call()
+    m = loader.MI355XCausalLM(SimpleNamespace())
+    m.mi355x_config = loader.MI355XConfig(on_device_sampling_config={"dynamic": True})
+    out = m.sample(torch.tensor([5, 9]))                         # on-device sampling: the "logits" ARE the sampled ids
+    assert out.sampled_token_ids.tolist() == [[5], [9]] and out.logprobs_tensors is None
+    m.mi355x_config = loader.MI355XConfig(on_device_sampling_config=None)
+    with pytest.raises(RuntimeError, match="CPU sampling should be handled by the model runner"):
+        m.sample(torch.zeros(2, 8))
+
+
+def test_artifact_directory_rules(tmp_path, monkeypatch):       # reference loader.py:160-226, 888-891
+    geo = {"num_layers": 2, "hidden_size": 256}
+    f = loader.MI355XCausalLM._artifact_dir
+    monkeypatch.delenv("MI355X_COMPILED_ARTIFACTS", raising=False)
+    # synthetic / in-memory weights are not cached unless a path is named
+    assert f("", {"synthetic_weights": {"seed": 1}}, geo, True, "f8e4m3", "per_channel_symmetric", 1) is None
+    assert f("", {"state_dict": {}}, geo, False, "int8", "per_tensor_symmetric", 1) is None
+    # quantized_checkpoints_path wins (quantized models only), then the environment variable
+    q = {"quantized_checkpoints_path": str(tmp_path / "q"), "state_dict": {}}
+    assert f("", q, geo, True, "f8e4m3", "per_channel_symmetric", 1) == str(tmp_path / "q")
+    assert f("", q, geo, False, "f8e4m3", "per_channel_symmetric", 1) is None          # not quantized: the key is ignored
+    monkeypatch.setenv("MI355X_COMPILED_ARTIFACTS", str(tmp_path / "env"))
+    assert f("", {"state_dict": {}}, geo, False, "int8", "per_tensor_symmetric", 1) == str(tmp_path / "env")
+    monkeypatch.delenv("MI355X_COMPILED_ARTIFACTS")
+    # a local checkpoint directory: <model>/mi355x-compiled-artifacts/<md5 of the configuration>
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    (ckpt / "model.safetensors").write_bytes(b"x" * 10)
+    a = f(str(ckpt), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1)
+    assert a.startswith(str(ckpt / "mi355x-compiled-artifacts")) and len(os.path.basename(a)) == 32
+    assert f(str(ckpt), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) == a      # stable
+    assert f(str(ckpt), {}, geo, True, "int8", "per_channel_symmetric", 1) != a        # another configuration
+    assert f(str(ckpt), {}, geo, True, "f8e4m3", "per_channel_symmetric", 8) != a      # another TP degree
+    assert f(str(ckpt), {"modules_to_not_convert": ["lm_head"]}, geo, True, "f8e4m3", "per_channel_symmetric", 1) != a
+    (ckpt / "model.safetensors").write_bytes(b"x" * 11)                                 # another checkpoint
+    assert f(str(ckpt), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) != a
+    assert f(str(tmp_path / "missing"), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) is None
