@@ -847,3 +847,32 @@ def test_artifact_directory_rules(tmp_path, monkeypatch):       # reference load
     (ckpt / "model.safetensors").write_bytes(b"x" * 11)                                 # another checkpoint
     assert f(str(ckpt), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) != a
     assert f(str(tmp_path / "missing"), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) is None
+
+
+def test_update_states_resume_after_preemption_and_kv_init():   # reference test_model_runner.py:823-873 (complex), :569-590
+    r = make_runner()
+    r.execute_model(sched_out([new_req("a", [1, 2, 3], [4, 5])]))
+    assert r.requests["a"].block_ids == ([4, 5],)
+    # preempted and resumed: the scheduler hands a NEW block list, which replaces the old one
+    cached = CachedRequestData(req_ids=["a"], resumed_from_preemption=[True], new_token_ids=[[]],
+                               new_block_ids=[([9, 8, 7],)], num_computed_tokens=[3])
+    r.execute_model(sched_out(cached=cached))
+    assert r.requests["a"].block_ids == ([9, 8, 7],)
+    kw = r.model.calls[-1]
+    assert kw["block_tables"][0, :3].tolist() == [9, 8, 7]       # the decode inputs follow the new blocks
+    pos = len(r.requests["a"].prompt_token_ids) + len(r.requests["a"].output_token_ids) - 2
+    assert kw["slot_mapping"][0].tolist() == [9 * 32 + pos]
+    # not resumed, nothing appended: the blocks stay
+    cached = CachedRequestData(req_ids=["a"], resumed_from_preemption=[False], new_token_ids=[[]],
+                               new_block_ids=[None], num_computed_tokens=[4])
+    r.execute_model(sched_out(cached=cached))
+    assert r.requests["a"].block_ids == ([9, 8, 7],)
+    # KV cache spec and initialisation (the library owns the pool: sized once, when vLLM has decided)
+    spec = r.get_kv_cache_spec()["layer"]
+    assert (spec.block_size, spec.num_kv_heads, spec.head_size, spec.dtype) == (32, 2, 64, torch.bfloat16)
+    calls = []
+    r.model.model = SimpleNamespace(finalize=lambda: calls.append("finalize"), set_num_blocks=lambda n: calls.append(("blocks", n)))
+    r._kv_ready = False
+    r.initialize_kv_cache(SimpleNamespace(num_blocks=77))
+    r.initialize_kv_cache(SimpleNamespace(num_blocks=99))        # second call: nothing
+    assert calls == [("blocks", 77), "finalize"]
