@@ -234,10 +234,32 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   __shared__ int cand_i[kSampleCand];
   __shared__ float red_v[kSampleThreads / 64];
   __shared__ int red_i[kSampleThreads / 64];
-  __shared__ unsigned int s_prefix, s_remaining, s_count;
+  __shared__ unsigned int s_prefix, s_remaining, s_count, s_neq;
+  __shared__ unsigned int wave_tot[4], wave_above[4], wave_cnt2[4];
+  __shared__ int wave_hi[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V = T * V_l;
-  auto at = [&](int v) -> float { return logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)]; };
+  auto at = [&](int v) -> float {
+    if (T == 1) return logits[(size_t)b * V_l + v];          // one part: no division per element
+    return logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)];
+  };
+  // one pass over the row: 8 independent loads in flight per thread (a single dependent load per iteration made
+  // every pass latency-bound: ~45 us per pass of a 128k vocabulary), elements visited in ascending index per thread
+  auto for_each = [&](auto&& fn) {
+    for (int v0 = tid; v0 < V; v0 += 8 * kSampleThreads) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * kSampleThreads;
+        x[u] = v < V ? at(v) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * kSampleThreads;
+        if (v < V) fn(v, x[u]);
+      }
+    }
+  };
   int top_k = 1;
   float top_p = 1.f, temperature = 1.f;
   if (params) {
@@ -250,10 +272,9 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   if (top_k == 1) {   // ---- greedy ----------------------------------------------------------
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = tid; v < V; v += kSampleThreads) {
-      const float x = at(v);
+    for_each([&](int v, float x) {
       if (x > bv) { bv = x; bi = v; }      // ascending v per thread: strict > keeps the lowest index
-    }
+    });
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const float ov = __shfl_xor(bv, off);
@@ -279,22 +300,63 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     __syncthreads();
     const unsigned int prefix = s_prefix;
     const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    for (int v = tid; v < V; v += kSampleThreads) {
-      const uint32_t key = f32_order_key(at(v));
-      if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {      // walk the bins from the top until the remaining rank falls inside one
-      unsigned int rem = s_remaining;
-      int bin = 255;
-      for (; bin > 0; --bin) {
-        if (hist[bin] >= rem) break;
-        rem -= hist[bin];
+    // a lane's consecutive elements mostly fall into the same bin on the first passes (sign / exponent bits):
+    // runs are counted in registers and added once, which takes the 64-way contention off the LDS atomics
+    unsigned int run_bin = 0xffffffffu, run_cnt = 0;
+    for_each([&](int, float x) {
+      const uint32_t key = f32_order_key(x);
+      if ((key & himask) == prefix) {
+        const unsigned int bin = (key >> shift) & 255u;
+        if (bin == run_bin) {
+          ++run_cnt;
+        } else {
+          if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
+          run_bin = bin;
+          run_cnt = 1;
+        }
       }
-      s_prefix = prefix | ((unsigned)bin << shift);
-      s_remaining = rem;
-    }
+    });
+    if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
     __syncthreads();
+    // the bin the remaining rank falls into: the highest bin whose suffix count (this bin and all above) reaches
+    // it.  Four waves hold the 256 bins: suffix sums inside a wave by shuffles, the waves' totals through LDS.
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      unsigned int cnt = 0, suf = 0;
+      if (tid < 256) {
+        cnt = hist[tid];
+        suf = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned int up = __shfl_down(suf, off);
+          if (lane + off < 64) suf += up;
+        }
+        if (lane == 0) wave_tot[wv] = suf;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = wv + 1; w < 4; ++w) suf += wave_tot[w];
+        const unsigned int rem = s_remaining;
+        const unsigned long long ok = __ballot(suf >= rem);
+        if (lane == 0) wave_hi[wv] = ok ? 63 - __builtin_clzll(ok) : -1;
+        if (ok && lane == 63 - __builtin_clzll(ok)) { wave_above[wv] = suf - cnt; wave_cnt2[wv] = cnt; }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int bin = 0;
+        unsigned int above = 0, here = hist[0];
+        bool found = false;
+        for (int w = 3; w >= 0 && !found; --w)
+          if (wave_hi[w] >= 0) { bin = w * 64 + wave_hi[w]; above = wave_above[w]; here = wave_cnt2[w]; found = true; }
+        if (!found) {   // (cannot happen while the counts are consistent: the serial walk ended at bin 0 with what was left)
+          above = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3] - hist[0];
+        }
+        s_prefix = prefix | ((unsigned)bin << shift);
+        s_remaining = s_remaining - above;
+        if (pass == 3) s_neq = here;   // all 32 bits fixed: the logits EQUAL to the threshold
+      }
+      __syncthreads();
+    }
   }
   const uint32_t kth = s_prefix;          // key of the top_k-th largest element
   // ---- candidates: exactly top_k of them ---------------------------------------------------
@@ -305,20 +367,24 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   //    candidate buffer with ties and drop larger logits, and depended on thread timing.)
   __shared__ unsigned int wave_cnt[kSampleThreads / 64];
   __shared__ unsigned int s_ties;
+  const unsigned int need = s_remaining;                   // ties to take (>= 1: the threshold element itself)
+  const unsigned int n_gt = (unsigned)top_k - need;        // logits strictly above the threshold
+  const bool all_ties = s_neq == need;                     // every logit at the threshold is taken: no order to respect
   if (tid == 0) { s_count = 0; s_ties = 0; }
   for (int i = tid; i < kSampleCand; i += kSampleThreads) { cand_v[i] = -INFINITY; cand_i[i] = 0x7fffffff; }
   __syncthreads();
-  for (int v = tid; v < V; v += kSampleThreads) {
-    const float x = at(v);
-    if (f32_order_key(x) > kth) {
+  for_each([&](int v, float x) {
+    const uint32_t key = f32_order_key(x);
+    if (key > kth) {
       const unsigned int slot = atomicAdd(&s_count, 1u);
-      if (slot < (unsigned)kSampleCand) { cand_v[slot] = x; cand_i[slot] = v; }
+      if (slot < n_gt) { cand_v[slot] = x; cand_i[slot] = v; }
+    } else if (all_ties && key == kth) {
+      const unsigned int slot = n_gt + atomicAdd(&s_ties, 1u);
+      if (slot < (unsigned)top_k) { cand_v[slot] = x; cand_i[slot] = v; }
     }
-  }
+  });
   __syncthreads();
-  const unsigned int n_gt = min(s_count, (unsigned)top_k);
-  const unsigned int need = (unsigned)top_k - n_gt;        // ties to take (>= 1: the threshold element itself)
-  for (int base = 0; base < V; base += kSampleThreads) {
+  for (int base = 0; base < V && !all_ties; base += kSampleThreads) {   // more ties than places: the lowest indices, in order
     if (s_ties >= need) break;                              // uniform: written behind the barrier below
     const int v = base + tid;
     const float x = v < V ? at(v) : 0.f;
@@ -338,11 +404,16 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     if (tid == 0) s_ties += total;
     __syncthreads();
   }
-  // bitonic sort of the kSampleCand slots: value descending, index ascending (deterministic)
-  for (int size = 2; size <= kSampleCand; size <<= 1) {
+  // bitonic sort of the first P slots (P = the power of two that holds top_k; the slots behind top_k are -inf
+  // fillers): value descending, index ascending (deterministic)
+  int P = 2;
+  while (P < top_k) P <<= 1;
+  __syncthreads();
+  if (tid >= kSampleMaxTopK) return;   // P <= 256 slots are sorted by the first four waves alone: their barriers are the cheap ones
+  for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       const int i = tid, j = i ^ stride;
-      if (j > i) {
+      if (j > i && j < P) {
         const bool desc = (i & size) == 0;
         const float vi = cand_v[i], vj = cand_v[j];
         const int ii = cand_i[i], ij = cand_i[j];
@@ -355,17 +426,23 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
       __syncthreads();
     }
   }
-  if (tid == 0) {        // <= 256 entries: serial fp32 arithmetic in a fixed order
+  // the exponentials in parallel (one per sorted candidate), the sums serially in a fixed order
+  float* cand_e = reinterpret_cast<float*>(hist);   // the histogram is dead: room for kSampleMaxTopK floats
+  {
     const float lmax = cand_v[0];
     const float inv_t = 1.f / temperature;
+    if (tid < top_k) cand_e[tid] = expf((cand_v[tid] - lmax) * inv_t);
+  }
+  __syncthreads();
+  if (tid == 0) {        // <= 256 entries: serial fp32 additions
     float total = 0.f;
-    for (int i = 0; i < top_k; ++i) total += expf((cand_v[i] - lmax) * inv_t);
+    for (int i = 0; i < top_k; ++i) total += cand_e[i];
     const float limit = top_p * total;
     float kept = 0.f;
     int nkeep = 0;
     for (int i = 0; i < top_k; ++i) {
       if (i > 0 && !(kept < limit)) break;
-      kept += expf((cand_v[i] - lmax) * inv_t);
+      kept += cand_e[i];
       nkeep = i + 1;
     }
     const unsigned long long r = splitmix64(seed ^ splitmix64(0x5EEDull + (unsigned long long)(row0 + b)));
@@ -374,7 +451,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     float cum = 0.f;
     int pick = nkeep - 1;
     for (int i = 0; i < nkeep; ++i) {
-      cum += expf((cand_v[i] - lmax) * inv_t);
+      cum += cand_e[i];
       if (cum > target) { pick = i; break; }
     }
     tokens[b] = cand_i[pick];
