@@ -220,6 +220,7 @@ int launch_fill_f32(float* out, size_t n, float v, hipStream_t s) {
 constexpr int kSampleThreads = 1024;
 constexpr int kSampleMaxTopK = 256;
 constexpr int kSampleCand = 1024;   // candidates kept for the sort (top_k plus ties at the threshold)
+constexpr int kSampleList = 4096;   // logits sharing the threshold's top key byte, set aside after the first pass
 
 __device__ __forceinline__ uint32_t f32_order_key(float f) {
   const uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -237,6 +238,15 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   __shared__ unsigned int s_prefix, s_remaining, s_count, s_neq;
   __shared__ unsigned int wave_tot[4], wave_above[4], wave_cnt2[4];
   __shared__ int wave_hi[4];
+  // After a pass only the logits inside the selected key range can still be the threshold (the ones above it are
+  // candidates for certain).  As soon as that range holds few enough -- after the second pass at the latest for any
+  // realistic row: a top byte covers two binades, two bytes 1/64 of one -- the next pass copies them aside and the
+  // remaining passes walk that list instead of the vocabulary.
+  __shared__ float list_v[kSampleList];
+  __shared__ int list_i[kSampleList];
+  __shared__ unsigned int s_list_n;
+  __shared__ int s_compact;
+  __shared__ unsigned int s_ties;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V = T * V_l;
   auto at = [&](int v) -> float {
@@ -292,7 +302,8 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   }
 
   // ---- radix select: the key of the top_k-th largest logit --------------------------------
-  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)top_k; }
+  if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)top_k; s_count = 0; s_ties = 0; s_list_n = 0; s_compact = 0; }
+  for (int i = tid; i < kSampleCand; i += kSampleThreads) { cand_v[i] = -INFINITY; cand_i[i] = 0x7fffffff; }
   __syncthreads();
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
@@ -303,8 +314,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     // a lane's consecutive elements mostly fall into the same bin on the first passes (sign / exponent bits):
     // runs are counted in registers and added once, which takes the 64-way contention off the LDS atomics
     unsigned int run_bin = 0xffffffffu, run_cnt = 0;
-    for_each([&](int, float x) {
-      const uint32_t key = f32_order_key(x);
+    auto count = [&](uint32_t key) {
       if ((key & himask) == prefix) {
         const unsigned int bin = (key >> shift) & 255u;
         if (bin == run_bin) {
@@ -315,7 +325,31 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
           run_cnt = 1;
         }
       }
-    });
+    };
+    // s_compact: 0 = walking the vocabulary, 1 = THIS pass walks it for the last time and sets the survivors aside
+    // (the bin selected so far holds few enough), 2 = walking the list
+    const int compact = s_compact;
+    if (compact == 2) {
+      const unsigned int n = s_list_n;
+      for (unsigned int i = tid; i < n; i += kSampleThreads) count(f32_order_key(list_v[i]));
+    } else if (compact == 1) {   // certain candidates (above the selected range) out, the selected range's logits aside
+      for_each([&](int v, float x) {
+        const uint32_t key = f32_order_key(x);
+        const uint32_t hi = key & himask;
+        if (hi > prefix) {
+          const unsigned int slot = atomicAdd(&s_count, 1u);   // fewer than top_k of them by construction
+          cand_v[slot] = x;
+          cand_i[slot] = v;
+        } else if (hi == prefix) {
+          const unsigned int slot = atomicAdd(&s_list_n, 1u);
+          list_v[slot] = x;
+          list_i[slot] = v;
+          count(key);
+        }
+      });
+    } else {
+      for_each([&](int, float x) { count(f32_order_key(x)); });
+    }
     if (run_cnt) atomicAdd(&hist[run_bin], run_cnt);
     __syncthreads();
     // the bin the remaining rank falls into: the highest bin whose suffix count (this bin and all above) reaches
@@ -353,6 +387,8 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
         }
         s_prefix = prefix | ((unsigned)bin << shift);
         s_remaining = s_remaining - above;
+        if (s_compact == 1) s_compact = 2;                                        // this pass has built the list
+        else if (s_compact == 0 && pass < 3 && here <= (unsigned)kSampleList) s_compact = 1;   // the next pass builds it
         if (pass == 3) s_neq = here;   // all 32 bits fixed: the logits EQUAL to the threshold
       }
       __syncthreads();
@@ -366,14 +402,10 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   //    order.  (Collecting ">= threshold" in arrival order, as a first version did, could fill the
   //    candidate buffer with ties and drop larger logits, and depended on thread timing.)
   __shared__ unsigned int wave_cnt[kSampleThreads / 64];
-  __shared__ unsigned int s_ties;
   const unsigned int need = s_remaining;                   // ties to take (>= 1: the threshold element itself)
   const unsigned int n_gt = (unsigned)top_k - need;        // logits strictly above the threshold
   const bool all_ties = s_neq == need;                     // every logit at the threshold is taken: no order to respect
-  if (tid == 0) { s_count = 0; s_ties = 0; }
-  for (int i = tid; i < kSampleCand; i += kSampleThreads) { cand_v[i] = -INFINITY; cand_i[i] = 0x7fffffff; }
-  __syncthreads();
-  for_each([&](int v, float x) {
+  auto collect = [&](int v, float x) {
     const uint32_t key = f32_order_key(x);
     if (key > kth) {
       const unsigned int slot = atomicAdd(&s_count, 1u);
@@ -382,7 +414,13 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
       const unsigned int slot = n_gt + atomicAdd(&s_ties, 1u);
       if (slot < (unsigned)top_k) { cand_v[slot] = x; cand_i[slot] = v; }
     }
-  });
+  };
+  if (s_compact == 2) {   // the logits above the selected range are in already (list-building pass); the rest come from the list
+    const unsigned int n = s_list_n;
+    for (unsigned int i = tid; i < n; i += kSampleThreads) collect(list_i[i], list_v[i]);
+  } else {
+    for_each(collect);
+  }
   __syncthreads();
   for (int base = 0; base < V && !all_ties; base += kSampleThreads) {   // more ties than places: the lowest indices, in order
     if (s_ties >= need) break;                              // uniform: written behind the barrier below
