@@ -256,17 +256,21 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
   // one pass over the row: 8 independent loads in flight per thread (a single dependent load per iteration made
   // every pass latency-bound: ~45 us per pass of a 128k vocabulary), elements visited in ascending index per thread
   auto for_each = [&](auto&& fn) {
-    for (int v0 = tid; v0 < V; v0 += 8 * kSampleThreads) {
-      float x[8];
+    for (int part = 0; part < T; ++part) {   // vocabulary-parallel logits: one slice per rank, walked in rank order (no division per element)
+      const float* row = logits + ((size_t)part * row_stride + b) * V_l;
+      const int vbase = part * V_l;
+      for (int j0 = tid; j0 < V_l; j0 += 8 * kSampleThreads) {
+        float x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * kSampleThreads;
-        x[u] = v < V ? at(v) : 0.f;
-      }
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * kSampleThreads;
+          x[u] = j < V_l ? row[j] : 0.f;
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * kSampleThreads;
-        if (v < V) fn(v, x[u]);
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * kSampleThreads;
+          if (j < V_l) fn(vbase + j, x[u]);
+        }
       }
     }
   };
