@@ -395,10 +395,10 @@ def main():
     #      [B, V] fp32 logits cross PCIe every step), then with on-device sampling (B ids cross).
     g = torch.Generator().manual_seed(3)
 
-    def engine_decode_rate():
+    def engine_decode_rate(sampling=None):
         prompts = [torch.randint(0, hf.vocab_size, (900,), generator=g).tolist() for _ in range(MAX_NUM_SEQS)]
         t_ = time.perf_counter()
-        outs = eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=128))
+        outs = eng.generate(prompts, sampling or SamplingParams(temperature=0.0, max_tokens=128))
         dt = time.perf_counter() - t_
         ntok = sum(len(o.token_ids) for o in outs)
         first = max(o.ttft_s for o in outs)
@@ -407,6 +407,8 @@ def main():
     model_adapter = eng.worker.model_runner.model
     model_adapter.mi355x_config.on_device_sampling_config = {"dynamic": True, "deterministic": False}
     engine_dev = engine_decode_rate()
+    # ... and with requests that SAMPLE (top_k 50, top_p 0.9, temperature 0.8): the radix-select sampler instead of the argmax
+    engine_dev_sampled = engine_decode_rate(SamplingParams(temperature=0.8, top_k=50, top_p=0.9, max_tokens=128, ignore_eos=True))
     model_adapter.mi355x_config.on_device_sampling_config = None
 
     # ---- the same loop under vLLM's native scheduler (chunked prefill on): every step is a
@@ -551,6 +553,7 @@ def main():
                    "global_batch": MAX_NUM_SEQS, "ctx": DECODE_CTX},
         "engine_decode_tokens_per_s": engine_cpu,
         "engine_decode_tokens_per_s_on_device_sampling": engine_dev,
+        "engine_decode_tokens_per_s_on_device_sampling_top_k50_top_p09": engine_dev_sampled,
         "engine_decode_tokens_per_s_chunked_prefill_scheduler": engine_chunked,
         "ttft_p50_ms": ttft, "ttft_mode": "weight-only quantization (the parity path)",
         "ttft_p50_ms_fp8_activations": ttft_a8, "fp8_activation_first_token_agreement": agreement,
