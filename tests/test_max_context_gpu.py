@@ -98,3 +98,49 @@ def test_context_up_to_the_last_position():
     got, ref = model.forward(**d), oracle.forward(**d)
     assert (got - ref).abs().max().item() < 0.06
     model.close()
+
+
+def test_128k_window_prefix_equivalence_and_the_block_limit():
+    """131072-token model length (4096 blocks of 32: the most the context-encoding attention stages per sequence).
+    No oracle at this size (its score matrix is T x T); the size-independent property instead: a 70001-token
+    prompt encoded in one call gives the logits of the same prompt encoded as 65536 cached + 4465 new tokens,
+    and the two sequences then generate the same token-generation logits side by side."""
+    from vllm_neuron_amd._native import MI_Q, MI_W, NativeModel
+    cfg = zoo_config("tinyllama_like")
+    w = make_weights(cfg, seed=7)
+    maxlen = 131072
+    mb = maxlen // BS
+    nb = 1 + 2 * mb
+
+    def make(max_model_len):
+        return NativeModel(
+            num_layers=cfg.num_layers, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads,
+            num_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+            vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta, rope_type=0,
+            rope_factor=1.0, rope_low_freq_factor=1.0, rope_high_freq_factor=4.0, rope_original_max_position=0,
+            qkv_bias=0, tie_word_embeddings=0, num_blocks=nb, block_size=BS, max_num_seqs=2,
+            max_model_len=max_model_len, ctx_buckets=[8192, max_model_len], weight_dtype=MI_W["bf16"],
+            quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1, tp_degree=1, tp_rank=0, device_id=0,
+            use_graphs=1, prefill_fp8_activations=0)
+
+    with pytest.raises(Exception, match="4096 blocks"):
+        make(maxlen + BS)
+    m = make(maxlen)
+    m.load_state_dict(w)
+    m.finalize()
+    g = torch.Generator().manual_seed(17)
+    prompt = torch.randint(1, cfg.vocab_size, (70001,), generator=g).tolist()
+    blocks = [[1 + i * mb + j for j in range(mb)] for i in range(2)]
+    one = m.forward(**prefill_inputs(prompt, blocks[0], BS, maxlen)).clone()
+    m.forward(**prefill_inputs(prompt[:65536], blocks[1], BS, maxlen))
+    two = m.forward(**prefill_inputs(prompt, blocks[1], BS, maxlen, 65536)).clone()
+    assert torch.isfinite(one).all()
+    assert (one - two).abs().max().item() < 0.06
+    tok = int(one[0].argmax())
+    out = m.forward(**decode_inputs([tok, tok], [70001, 70001], blocks, BS, maxlen))
+    assert torch.isfinite(out).all()
+    assert (out[0] - out[1]).abs().max().item() < 0.06
+    # the last position of the window
+    out = m.forward(**decode_inputs([tok], [maxlen - 1], blocks[:1], BS, maxlen))
+    assert torch.isfinite(out).all()
+    m.close()

@@ -31,6 +31,8 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
 // only ever touched by these launches (which leave them at zero): enables the in-launch merge
 
 // One sequence: q [T, nh, hd] at absolute positions q_pos0.., keys 0..q_pos0+T-1 from the pool.
+// The sequence's block table is staged in LDS once: at most kPrefillMaxBlocks blocks (131072 tokens at block_size 32).
+constexpr int kPrefillMaxBlocks = 4096;
 int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kpool,
                         const uint16_t* vpool, int block_size, const int32_t* block_table, int nh,
                         int nkv, int hd, uint16_t* out, hipStream_t s);

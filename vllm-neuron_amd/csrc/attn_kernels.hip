@@ -439,7 +439,6 @@ int launch_attn_decode(const uint16_t* q, const uint16_t* kpool, const uint16_t*
 // exponentiated accumulators are the B operand as they stand (no LDS round trip for P).  V stays
 // row-major in LDS; its transposed A fragments come from ds_read_b64_tr_b16 (4 keys x 16 dims
 // per 16-lane group).  Next tile's K/V are prefetched into registers under the MFMAs.
-constexpr int kPrefillMaxBlocks = 2048;
 
 template <int HD, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
@@ -679,7 +678,7 @@ int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kp
   MI_CHECK(hd == 64 || hd == 128, "attention: head_dim must be 64 or 128");
   MI_CHECK(T >= 1 && q_pos0 >= 0, "attention: bad T / q_pos0");
   MI_CHECK(nh % nkv == 0 && nh / nkv <= 8, "attention: q heads per kv head must be 1..8");
-  MI_CHECK(ceil_div(q_pos0 + T, block_size) <= kPrefillMaxBlocks, "attention: context spans too many blocks");
+  MI_CHECK(ceil_div(q_pos0 + T, block_size) <= kPrefillMaxBlocks, "attention: context spans more than 4096 blocks");
   const int G = nh / nkv;
   const int Gp = G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8));
   const int waves = Gp < 4 ? 4 : Gp, QB = waves / Gp;

@@ -605,6 +605,8 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   // context-encoding GEMMs (vLLM's default max_num_seqs for this platform is 32, platform.py)
   MI_CHECK(k.max_num_seqs >= 1 && k.max_num_seqs <= 256, "max_num_seqs must be 1..256");
   MI_CHECK(k.max_model_len >= 1, "max_model_len");
+  MI_CHECK(ceil_div(k.max_model_len, k.block_size) <= kPrefillMaxBlocks,
+           "max_model_len spans more than 4096 blocks per sequence: raise block_size (context encoding stages a sequence's block table in LDS)");
   MI_CHECK(k.weight_dtype >= MI_W_BF16 && k.weight_dtype <= MI_W_INT8, "weight_dtype");
   MI_CHECK(k.quant_type == MI_Q_PER_TENSOR_SYMMETRIC || k.quant_type == MI_Q_PER_CHANNEL_SYMMETRIC, "quant_type");
   int ndev = 0;
