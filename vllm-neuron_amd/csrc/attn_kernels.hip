@@ -445,10 +445,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
     const uint16_t* __restrict__ q, int T, int q_pos0, const uint16_t* __restrict__ kpool,
     const uint16_t* __restrict__ vpool, int bs, const int32_t* __restrict__ block_table, int nh, int nkv, int G,
     int Gp, int paired, uint16_t* __restrict__ out, float scale_log2e) {
-  // row pitch (elements).  head_dim 128: 288 B = 72 banks, so the 16 rows of a ds_read_b128 lane group start 8 banks apart
-  // (its lanes of the next 16-byte column fill the gaps) and the 8 rows of a ds_read_b64_tr_b16 group own 8 banks each:
-  // no conflicts (at 272 B one pair of lanes per group met on a bank: 37 % of the LDS cycles, SQ_LDS_BANK_CONFLICT)
-  constexpr int KP = HD + (HD == 128 ? 16 : 8);
+  // row pitch (elements): head_dim + 16, i.e. 288 B = 72 banks (head_dim 128) or 160 B = 40 banks (64).  Either way the 16 rows
+  // of a ds_read_b128 lane group start on 16 different 4-bank windows (its lanes of the next 16-byte column take the windows in
+  // between) and the 8 rows of a ds_read_b64_tr_b16 group own 8 banks each: no conflicts.  (At head_dim + 8 one pair of lanes
+  // per group met on a bank: 37 % of the LDS cycles, SQ_LDS_BANK_CONFLICT.)
+  constexpr int KP = HD + 16;
   constexpr int CPR = HD / 8;   // 16-byte chunks per row
   constexpr int DN = HD / 16, KS = HD / 32;
   constexpr int TK = 64;        // keys per tile
