@@ -486,7 +486,7 @@ def main():
         native.forward(**inp)                               # the full graph again (and a meaningful state)
         achieved = gemv_bytes / (gemv_ms * 1e-3) / 1e9
         # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
-        # gfx950-corrected; tests/pmc_summary.py) -- counters cannot be read from inside the process
+        # gfx950-corrected; tools/pmc_summary.py) -- counters cannot be read from inside the process
         traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "r02_gemv_traffic.json")
         if args.model == "llama31_8b" and wd == "f8e4m3" and os.path.exists(tf):

@@ -51,7 +51,7 @@ def fused_speculation_step(target: PagedDecoderOracle, draft: PagedDecoderOracle
     next_pos = torch.zeros(B, dtype=torch.long)
     for b in range(B):
         pos, row = int(positions[b]), block_table[b]
-        lim = min(k, max_model_len - pos)                      # candidate rows that fit the model length
+        lim = max(1, min(k, max_model_len - pos - 1))          # candidate rows: the sequence stays within max_model_len tokens
         cand = [int(last_tokens[b])]
         # the draft sees every candidate here; the HIP path runs k - 1 draft steps and feeds the last candidate
         # to the draft at the start of the NEXT step when (and only when) it was accepted -- the same K/V

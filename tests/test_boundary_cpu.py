@@ -399,6 +399,16 @@ def test_decode_input_contract_and_block_append():              # runner.py:765-
                                new_block_ids=[([20, 21],), None], num_computed_tokens=[32, 41])
     r.execute_model(sched_out(cached=cached))
     assert r.requests["a"].block_ids == ([20, 21],)
+    # ... and the TENSOR handed to the model follows, although the new list is as long as the old
+    # one (the persistent row used to be rewritten only on a length change)
+    kw = r.model.calls[-1]
+    assert kw["block_tables"][0, :3].tolist() == [20, 21, 0] and kw["block_tables"][1, :3].tolist() == [6, 7, 0]
+    assert kw["slot_mapping"][0].tolist() == [21 * 32 + 0]         # position 32 -> second block of the new list
+    # same length again, not resumed: the row is kept (and stays right)
+    cached = CachedRequestData(req_ids=["a", "b"], resumed_from_preemption=[False, False], new_token_ids=[[], []],
+                               new_block_ids=[None, None], num_computed_tokens=[33, 42])
+    r.execute_model(sched_out(cached=cached))
+    assert r.model.calls[-1]["block_tables"][0, :3].tolist() == [20, 21, 0]
 
 
 def test_incremental_decode_inputs_equal_the_rebuilt_ones():

@@ -200,10 +200,12 @@ def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
         acc, nxt = target.forward_spec(draft, torch.tensor([seq[-1]]), torch.tensor([pos]), bt, K, catchup_ids=cu.ids([pos]))
         cu.record([pos], acc, nxt, K)
         n = int(nxt[0]) - pos
-        full_windows += n == min(K, MAXLEN - pos)
-        assert 1 <= n <= min(K, MAXLEN - pos)
+        lim = max(1, min(K, MAXLEN - pos - 1))                    # a window never takes the sequence past MAXLEN tokens
+        full_windows += n == lim
+        assert 1 <= n <= lim
         seq.extend(acc[0, :n].tolist())
-    assert L + len(seq) == MAXLEN + 1 and full_windows >= 9       # the draft is a copy and is caught up: full windows, the last one clipped
+        assert L + len(seq) <= MAXLEN or pos == MAXLEN - 1        # (the step at the last position yields its one token, like the plain step)
+    assert L + len(seq) == MAXLEN + 1 and full_windows >= 9       # the draft is a copy and is caught up: full windows, the last ones clipped
     # the same text from the target alone (fresh blocks)
     blocks2 = [[20, 21, 22, 23, 24, 25, 26, 27]]
     want = _plain_greedy(target, [p], blocks2, len(seq))
@@ -271,6 +273,33 @@ def test_engine_with_speculative_config_generates_the_target_text(draft_kind, qu
         _, out = eng.step()
         assert all(len(t) <= 1 for t in out.sampled_token_ids)
     assert len(eng.outputs[rid].token_ids) == 6 and eng.outputs[rid].finished
+    runner = eng.worker.model_runner
+    runner.model.draft.close()
+    runner.model.model.close()
+
+
+def test_engine_speculation_runs_a_request_up_to_max_model_len():
+    """a greedy request that runs to the model length with an agreeing draft used to leave
+    max_model_len + 1 tokens (runner assertion).  The last windows are clipped so that the sequence
+    ends at exactly max_model_len tokens, with the plain engine's text."""
+    from vllm_neuron_amd._vllm_compat import SamplingParams, SimpleModelConfig, SimpleSpeculativeConfig
+    from vllm_neuron_amd.engine import MI355XEngine
+    cfg = zoo_config("tinyllama_like")
+    w = make_weights(cfg, seed=2)
+    MAXL = 96
+    g = torch.Generator().manual_seed(11)
+    prompt = torch.randint(0, cfg.vocab_size, (70,), generator=g).tolist()
+    sp = SamplingParams(temperature=0.0, max_tokens=1000, ignore_eos=True)
+    plain = MI355XEngine(_hf_like(cfg), max_model_len=MAXL, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                         override_mi355x_config={"state_dict": w})
+    want = plain.generate([prompt], sp)[0].token_ids
+    plain.worker.model_runner.model.model.close()
+    assert len(prompt) + len(want) == MAXL
+    spec = SimpleSpeculativeConfig(num_speculative_tokens=K, draft_model_config=SimpleModelConfig(model="", hf_config=_hf_like(cfg)))
+    eng = MI355XEngine(_hf_like(cfg), max_model_len=MAXL, max_num_seqs=4, block_size=32, enable_prefix_caching=True,
+                       speculative_config=spec, override_mi355x_config={"state_dict": w, "draft_state_dict": w})
+    got = eng.generate([prompt], sp)[0].token_ids
+    assert got == want
     runner = eng.worker.model_runner
     runner.model.draft.close()
     runner.model.model.close()

@@ -1,5 +1,5 @@
 """Dev tool: engine decode rate under vLLM's native scheduler (chunked prefill on): 4 requests of 900 prompt
-tokens, 128 new tokens each.    python tests/chunked_rate.py [max_num_batched_tokens=2048]
+tokens, 128 new tokens each.    python tools/chunked_rate.py [max_num_batched_tokens=2048]
 A small budget (256) makes most steps MIXED records (a prompt chunk + requests that generate)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

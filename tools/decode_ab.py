@@ -1,5 +1,5 @@
 """Dev tool: device-resident decode step time (graph replay) of the Llama-3.1-8B shapes.
-    python tests/decode_ab.py [wd=f8e4m3] [ctx=1024] [steps=200] [model=llama|qwen]"""
+    python tools/decode_ab.py [wd=f8e4m3] [ctx=1024] [steps=200] [model=llama|qwen]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 """Dev tool: one context-encoding GEMM shape through mi_op_qlinear (path 2 = 128x128 kernel, 3 = wide-N
 LDS-DMA kernel), timed with events; run under rocprofv3 --pmc for counters.
-    python tests/gemm_probe.py M N K path [wd]"""
+    python tools/gemm_probe.py M N K path [wd]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc -o bench -- \
         python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --ttft-prompts 1
-    python tests/pmc_summary.py gpurun_out/pmc profiles/r01_gemv_traffic.json
+    python tools/pmc_summary.py gpurun_out/pmc profiles/r01_gemv_traffic.json
 
 Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM): FETCH_SIZE is in KiB and on gfx950
 reports exactly half of the bytes of a wide coalesced streaming read -> bytes = value * 1024 * 2.

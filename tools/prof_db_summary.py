@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd database (kernel trace): per kernel x grid, calls / median / min us.
-    python tests/prof_db_summary.py <dir-or-db> [top N]"""
+    python tools/prof_db_summary.py <dir-or-db> [top N]"""
 import collections, glob, os, sqlite3, sys
 d = sys.argv[1]
 f = d if d.endswith(".db") else sorted(glob.glob(d + "/**/*_results.db", recursive=True), key=os.path.getmtime)[-1]

@@ -7,6 +7,6 @@ timeout -k 10 600 python3 bench.py > $OUT/r02_bench_n1.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r02 -- python3 /root/repo/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r02_bench_n1_under_rocprof.json 2> $OUT/kt.err
 cd /root/repo
-python3 tests/prof_summary.py /tmp/kt 60 > $OUT/r02_bench_n1_kernel_summary.txt
+python3 tools/prof_summary.py /tmp/kt 60 > $OUT/r02_bench_n1_kernel_summary.txt
 cp /tmp/kt/r02_kernel_stats.csv $OUT/r02_bench_n1_kernel_stats.csv
 tail -c 600 $OUT/r02_bench_n1.json

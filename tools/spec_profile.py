@@ -1,5 +1,5 @@
 """Dev tool: per-kernel-class time of a token-generation pass at M rows (the target's pass of a speculation step).
-    python tests/spec_profile.py [rows=16] [k=4]"""
+    python tools/spec_profile.py [rows=16] [k=4]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace

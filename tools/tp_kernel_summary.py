@@ -2,7 +2,7 @@
 `bench.py --gpus T --tp-loopback` (every rank shard on one GPU, one stream): the trace holds the
 kernels of all T ranks back to back, so (sum of durations of the step's kernels) / T is the compute
 one GPU would spend per step with a free exchange, and the ar_* rows are the exchange kernels'
-single-GPU cost.    python tests/tp_kernel_summary.py <trace dir> T"""
+single-GPU cost.    python tools/tp_kernel_summary.py <trace dir> T"""
 import collections, csv, glob, json, os, sys
 d, T = sys.argv[1], int(sys.argv[2])
 f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]

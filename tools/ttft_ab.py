@@ -1,5 +1,5 @@
 """Dev tool: context-encoding time per bucket through mi_forward (weight-only and FP8 x FP8), Llama-3.1-8B shapes.
-    python tests/ttft_ab.py [a8=0|1]"""
+    python tools/ttft_ab.py [a8=0|1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

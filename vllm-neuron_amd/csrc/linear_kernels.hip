@@ -383,7 +383,7 @@ __device__ __forceinline__ float gemv_row_rinv(const float* ssq, int m, int K, f
   return rsqrtf(tot / (float)K + eps);
 }
 
-// Phase timeline of the decode GEMVs (dev builds only: -DMI_TRACE, see tests/trace_gemv.py).
+// Phase timeline of the decode GEMVs (dev builds only: -DMI_TRACE, see tools/trace_gemv.py).
 // Wave 0 of every work-group stamps the 100 MHz wall clock at fixed points into
 // g_trace_buf[launch % kTraceLaunches][block][stamp]; launches are numbered by a device counter.
 #ifdef MI_TRACE
@@ -603,7 +603,7 @@ __device__ __forceinline__ void pin_gemv_args(const uint4* W, int NT, int KT, in
 // =====================================================================================
 // GEMV, wave-private staging (the short K-split projections: QKV, O, down at M <= 4)
 // =====================================================================================
-// In-kernel timeline of gemv_kernel on the Llama-8B decode shapes (tests/trace_gemv.py, us, median
+// In-kernel timeline of gemv_kernel on the Llama-8B decode shapes (tools/trace_gemv.py, us, median
 // work-group): issue 1.2-1.7 | stage 2.0-2.9 | barrier 0.7-1.6 | first batch 1.0-1.5 | stream 1.0 (O)
 // ... 13.4 (gate|up).  For O-proj the 64 KiB a CU streams are 1 us of a 7 us kernel: the rest is the
 // serial chain kernel entry -> index arithmetic (runtime divisions) -> x from L2 -> LDS -> work-group
@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
     load_w(wr, ks_beg);
   }
   for (int ks = ks_beg; ks < nks; ++ks) {
-    if (ks == ks_beg + 4) MI_STAMP(1);     // tests/trace_gemm.py: phases of the fifth K-step
+    if (ks == ks_beg + 4) MI_STAMP(1);     // tools/trace_gemm.py: phases of the fifth K-step
     if (ks == ks_beg + 5) MI_STAMP(6);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

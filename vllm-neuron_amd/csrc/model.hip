@@ -1401,12 +1401,15 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   for (int b = 0; b < B; ++b) {
     const int64_t pos = position_ids[b];
     MI_CHECK(pos >= 0 && pos < kt.max_model_len, "position out of range");
-    MI_CHECK(ceil_div((int)pos + (int)std::min<int64_t>(k, kt.max_model_len - pos), kt.block_size) <= MB,
+    MI_CHECK(ceil_div((int)pos + (int)std::max<int64_t>(1, std::min<int64_t>(k, kt.max_model_len - pos - 1)), kt.block_size) <= MB,
              "block_table narrower than the speculation window");
   }
   const size_t ms = (size_t)kt.max_num_seqs;
   const int bs = kt.block_size;
-  auto lim_of = [&](int b) { return (int)std::min<int64_t>(k, kt.max_model_len - position_ids[b]); };   // candidate rows that fit the model length
+  // Candidate rows that fit the model length.  A step that feeds position pos holds pos + 1 tokens and may
+  // yield one token per candidate row, and vLLM caps a sequence at max_model_len tokens (its runner's
+  // token table is that wide): at most max_model_len - pos - 1 rows, and never fewer than the plain step's one.
+  auto lim_of = [&](int b) { return (int)std::max<int64_t>(1, std::min<int64_t>(k, kt.max_model_len - position_ids[b] - 1)); };
   auto slot_of = [&](int b, int64_t p) { return block_table[(size_t)b * MB + p / bs] * bs + p % bs; };
   static const bool shared_cols = [] { const char* v = getenv("MI355X_SPEC_SHARED_ATTN"); return !v || v[0] != '0'; }();
   // the k rows of a sequence share the attention's MFMA columns where they fit (q heads per kv head x k <= 16)

@@ -313,8 +313,9 @@ class MI355XModelRunner:
         pad = -1 if (cfg.attn_tkg_nki_kernel_enabled or cfg.attn_block_tkg_nki_kernel_enabled) else self._BLOCK_TABLE_PAD
         if st is None or st["pad"] != pad:
             st = self._decode_state = {"pad": pad, "rows": [None] * self.max_num_reqs, "nblk": [0] * self.max_num_reqs,
+                                       "tbl": [None] * self.max_num_reqs,
                                        "bt": torch.full((self.max_num_reqs, mb), pad, dtype=torch.long)}
-        bt, rows, nblk = st["bt"], st["rows"], st["nblk"]
+        bt, rows, nblk, tbl = st["bt"], st["rows"], st["nblk"], st["tbl"]
         tokens, positions, seq_ids, slots = [], [], [], []
         for i, req_id in enumerate(req_ids):
             assert req_id in self.vllm_req_to_seq_id_mapping, (
@@ -322,11 +323,14 @@ class MI355XModelRunner:
             state = self.requests[req_id]
             block_table = state.block_ids[0]
             position = len(state.prompt_token_ids) + len(state.output_token_ids) - 1
-            if rows[i] != req_id:                    # another request moved into this row
+            # `_update_states` extends a request's block list in place and REPLACES the list object
+            # when the request resumes after a preemption (possibly with as many blocks as before):
+            # the row is rebuilt whenever the request or the list object behind it changed.
+            if rows[i] != req_id or tbl[i] is not block_table:
                 bt[i].fill_(pad)
                 bt[i, :len(block_table)] = torch.as_tensor(block_table, dtype=torch.long)
-                rows[i], nblk[i] = req_id, len(block_table)
-            elif nblk[i] != len(block_table):        # blocks appended (or replaced after a preemption)
+                rows[i], nblk[i], tbl[i] = req_id, len(block_table), block_table
+            elif nblk[i] != len(block_table):        # blocks appended
                 if len(block_table) < nblk[i]:
                     bt[i, len(block_table):nblk[i]] = pad
                 bt[i, :len(block_table)] = torch.as_tensor(block_table, dtype=torch.long)
@@ -336,7 +340,7 @@ class MI355XModelRunner:
             seq_ids.append(self.vllm_req_to_seq_id_mapping[req_id])
             slots.append(self._decode_slots(block_table, position))
         for i in range(n, self.max_num_reqs):
-            rows[i] = None
+            rows[i] = tbl[i] = None
         pos_t = torch.tensor(positions, dtype=torch.long).reshape(n, 1)
         input_tokens = torch.tensor(tokens, dtype=torch.long).reshape(n, 1)
         return ModelInputForMI355X(
