@@ -219,10 +219,11 @@ def test_paged_attn_decode(lib, hd, nh, nkv, ctx):
         assert err < 0.02, (b, ctx[b], err)      # bf16 output rounding of O(1) values
 
 
-@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 8, 1), (64, 7, 1)])
-@pytest.mark.parametrize("T,pos0", [(6, 0), (79, 0), (70, 70), (9, 64), (300, 0), (130, 96)])
-def test_paged_attn_prefill(lib, hd, nh, nkv, T, pos0):
-    bs, MB = 32, 16
+@pytest.mark.parametrize("hd,nh,nkv", [(128, 8, 2), (64, 8, 1), (64, 7, 1), (128, 2, 2), (128, 4, 2), (64, 4, 1)])
+@pytest.mark.parametrize("T,pos0,bs", [(6, 0, 32), (79, 0, 32), (70, 70, 32), (9, 64, 32), (300, 0, 32), (130, 96, 32),
+                                       (1, 200, 32), (33, 31, 16), (257, 0, 16), (500, 12, 48), (64, 0, 32), (65, 63, 32)])
+def test_paged_attn_prefill(lib, hd, nh, nkv, T, pos0, bs):
+    MB = (pos0 + T + bs - 1) // bs + 2
     nb = 1 + MB
     k, v = _make_pool(nb, bs, nkv, hd, 7)
     pool = dev(pool_to_native(k, v, nb, bs))
@@ -243,6 +244,42 @@ def test_paged_attn_prefill(lib, hd, nh, nkv, T, pos0):
     ref = ref_attention(q.float(), kk[blk, idx % bs], vv[blk, idx % bs], pos0 + torch.arange(T))
     err = (out.cpu().float() - ref).abs().max().item()
     assert err < 0.03, err     # P is rounded to bf16 before the P.V MFMA
+
+
+@pytest.mark.parametrize("T,pos0", [(1007, 0), (2031, 0), (1500, 517)])
+def test_paged_attn_prefill_long_and_the_rescale_branch(lib, T, pos0):
+    """Bucket-sized prompts at the Llama-8B head geometry (4 q heads per kv head, head_dim 128), scattered blocks, and a
+    spiked key late in the context: the deferred rescale of the running maximum (attn_prefill2_kernel: the exponent's
+    maximum only moves when a tile exceeds it by 2^6) must fire there -- a branch bounded random data never takes."""
+    hd, nh, nkv, bs = 128, 8, 2, 32
+    kv_len = pos0 + T
+    MB = (kv_len + bs - 1) // bs + 1
+    nb = 1 + MB
+    k, v = _make_pool(nb, bs, nkv, hd, 17)
+    perm = (torch.randperm(nb - 1, generator=torch.Generator().manual_seed(18)) + 1)
+    bt = torch.zeros(MB, dtype=torch.int32)
+    nblk = (kv_len + bs - 1) // bs
+    bt[:nblk] = perm[:nblk].int()
+    q = torch.randn(T, nh, hd, generator=torch.Generator().manual_seed(19)).to(torch.bfloat16)
+    # spike: key at position pos0 + T // 2 + 5 is 6 x the query at row T - 3 of head 1 (score ~ 6 |q|^2 / sqrt(hd) ~ 68)
+    spike_pos = pos0 + T // 2 + 5
+    kk = k.reshape(nb, bs, nkv, hd)
+    kk[int(bt[spike_pos // bs]), spike_pos % bs, 0] = (6 * q[T - 3, 1].float()).to(torch.bfloat16)
+    pool = dev(pool_to_native(k, v, nb, bs))
+    out = torch.empty(T, nh * hd, dtype=torch.bfloat16, device="cuda")
+    qd, btd = dev(q), dev(bt)
+    lib.check(lib.load_library().mi_op_paged_attn_prefill(qd.data_ptr(), T, pos0, pool.data_ptr(), nb, bs,
+                                                          btd.data_ptr(), MB, nh, nkv, hd, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    idx = torch.arange(kv_len)
+    blk = bt[idx // bs].long()
+    kf, vf = k.float().reshape(nb, bs, nkv, hd), v.float().reshape(nb, bs, nkv, hd)
+    ref = ref_attention(q.float(), kf[blk, idx % bs], vf[blk, idx % bs], pos0 + torch.arange(T))
+    err = (out.cpu().float() - ref).abs()
+    assert err.max().item() < 0.03, (err.max().item(), err.argmax().item())
+    # the spiked row attends almost only to the spiked key: its output is that key's V row
+    got = out.cpu().float().reshape(T, nh, hd)[T - 3, 1]
+    assert (got - vf[int(bt[spike_pos // bs]), spike_pos % bs, 0]).abs().max() < 0.05
 
 
 def test_errors_are_loud(lib):

@@ -18,6 +18,18 @@
 
 namespace mi {
 
+#define MI_TRY_A(expr)             \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != MI_OK) return _rc;  \
+  } while (0)
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses into 1 KiB of LDS starting at `l` (wave-uniform)
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // exp2(x - m) with the -inf conventions of online softmax (m finite or -inf)
 __device__ __forceinline__ float sexp2(float x, float m) {
@@ -676,6 +688,327 @@ __global__ __launch_bounds__(WAVES * 64) void attn_prefill_kernel(
   }  // pass
 }
 
+
+// =====================================================================================
+// context encoding, second generation: 32x32x16 MFMAs, K/V tiles by LDS-DMA, two waves per SIMD
+// =====================================================================================
+// What the counters of the kernel above asked for (17 % MFMA-busy at one wave per
+// SIMD, 408 registers, 144 accumulator moves and a ds_write staging pass per 64-key tile):
+//   * a wave owns ONE 32-query block of one q head: S^T[key][q] = K . Q^T on v_mfma_f32_32x32x16_bf16
+//     puts a query on a lane (its 32 scores of a 64-key tile in 32 registers of lanes l and l + 32), so
+//     the row maximum / sum is 31 VALU ops and ONE v_permlane32_swap, and the exponentiated
+//     accumulators, packed pairwise to bf16, ARE the B operand of O^T[d][q] += V^T . P^T (k-slot j of
+//     lane half h <-> key 16 s + 8 (j >> 2) + 4 h + (j & 3): the transposed V reads are bound to that order);
+//   * K and V tiles (64 keys) arrive by LDS-DMA (global_load_lds, 1 KiB per wave-instruction) into a
+//     ring of three 32 KiB stages: no staging registers, no ds_write, two tiles in flight while one is
+//     multiplied, retired by a counted vmcnt in front of ONE raw barrier per tile.  The paged pool is
+//     addressed per piece (4 keys x 256 B at head_dim 128): the block id is a scalar load, the per-lane
+//     part of the source address is constant for the whole kernel;
+//   * the LDS image is rows of head_dim bf16 whose 16-byte chunks are XOR-swizzled by the key (applied
+//     to the per-lane SOURCE address of the DMA and to the reads): conflict-free for the ds_read_b128
+//     row reads of K (16 lanes = 16 keys = 16 different slots) and for the ds_read_b64_tr_b16
+//     transposed reads of V (a half-wave's 4 keys land on 4 different 64-byte windows);
+//   * ~170 registers: two waves per SIMD.  A work-group is NW waves = QB query blocks x Gp q heads of
+//     one kv group, all sharing the K/V ring.  Causal work grows with the block index, so the QB blocks
+//     of a work-group are complementary pairs (j, nblk - 1 - j): every SIMD of the chip gets the same
+//     number of key tiles, and the light block's waves keep issuing DMAs for the heavy one's tail.
+// Softmax: the running maximum used in the exponent is only moved when the tile's maximum exceeds it
+// by more than kDeferLog2 (deferred rescale): p <= 2^kDeferLog2 instead of <= 1, O and l carry the
+// same factor, the quotient O / l is unchanged up to rounding; the 64-register rescale of O^T becomes rare.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr float kDeferLog2 = 6.f;
+
+// {v of this lane, v of lane ^ 32} in some order (max / sum do not care): one v_permlane32_swap.  The elements of the
+// builtin's result are copied out before the bit cast: hipcc 7.2 reads element 0 for __builtin_bit_cast(float, r[1])
+// (hipcc notes) -- which made a row's sum 2 x (its lower half's sum).
+__device__ __forceinline__ f32x2_t swap32_pair(float v) {
+  const unsigned a = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return f32x2_t{__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1)};
+}
+
+template <int HD>
+__device__ __forceinline__ int kv_swz(int key) {   // XOR key of the 16-byte chunk index of a K/V row in LDS
+  if constexpr (HD == 128) return ((key & 3) << 2) | ((key >> 2) & 3);          // 256-byte rows, 16 chunks
+  else return (((key >> 1) & 1) << 2) | ((key >> 2) & 3);                        // 128-byte rows,  8 chunks
+}
+
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_prefill2_kernel(
+    const uint16_t* __restrict__ q, int T, int q_pos0, const uint16_t* __restrict__ kpool,
+    const uint16_t* __restrict__ vpool, int bs, int bs_shift, const int32_t* __restrict__ block_table, int nh, int nkv,
+    int G, int Gp, int nblk, uint16_t* __restrict__ out, float scale_log2e) {
+  constexpr int TK = 64;                       // keys per tile
+  constexpr int ROWB = HD * 2;                 // bytes per K/V row
+  constexpr int CPR = HD / 8;                  // 16-byte chunks per row
+  constexpr int KPP = 1024 / ROWB;             // keys per 1 KiB DMA piece (4 / 8)
+  constexpr int NP = TK / KPP;                 // pieces per K (or V) tile (16 / 8)
+  constexpr int KBYTES = TK * ROWB;            // 16 / 8 KiB
+  constexpr int STAGE = 2 * KBYTES;
+  constexpr int NSTAGE = 3;
+  constexpr int PPW = NP / NW > 0 ? NP / NW : 1;   // K pieces per wave and tile (V the same)
+  static_assert(NP % NW == 0, "pieces must divide over the waves");
+  constexpr int CNT = 2 * PPW;                 // DMA instructions per wave and tile
+  constexpr int KSTEPS = HD / 16, DB = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kvh = blockIdx.y;
+  const int QB = NW / Gp;
+  const int hl = wave % Gp, slot = wave / Gp;
+  const int head = kvh * G + min(hl, G - 1);
+  const bool head_ok = hl < G;
+  const int kv_len = q_pos0 + T;
+  const int last_piece_key = ((kv_len - 1) / KPP) * KPP;
+  const int qq = lane & 31, h = lane >> 5;
+  const int npair = (nblk + 1) >> 1;
+
+  // ---- per-lane constants of the LDS image -------------------------------------------------------
+  // DMA: lane i of a piece fills slot (i % CPR) of key (i / CPR) of the piece: it fetches the chunk the swizzle puts there
+  const int kip = lane / CPR, dslot = lane % CPR;
+  int dma_sw;
+  if constexpr (HD == 128) dma_sw = (kip << 2) | (wave & 3);                 // kv_swz(4 piece + kip), piece = wave (mod 4)
+  else dma_sw = (((kip >> 1) & 1) << 2) | ((2 * (wave & 1) + (kip >> 2)) & 3);   // kv_swz(8 piece + kip), piece = wave (mod 2)
+  const int dma_lane_off = kip * HD + ((dslot ^ dma_sw) * 8);                // elements, relative to the piece's first row
+  // K row reads (A operand of S^T): key qq of a 32-key block, chunk 2 ks + h
+  int kaddr[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) kaddr[ks] = qq * ROWB + (((2 * ks + h) ^ kv_swz<HD>(qq)) * 16);
+  // V transposed reads (A operand of O^T): group gi = lane >> 4 covers dims 16 (gi & 1) .. + 15 of a 32-dim block for lane half
+  // h = gi >> 1; lane 4 qr + pc of the group addresses key row (4 h + qr [+ 8]) at dims 4 pc .. 4 pc + 3
+  const int gi = lane >> 4, qr = (lane & 15) >> 2, pc = lane & 3;
+  int vaddr[DB][2];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int key = 4 * h + qr + 8 * u;                                     // (+ 32 b + 16 s: no effect on the swizzle key)
+      const int chunk = 4 * db + 2 * (gi & 1) + (pc >> 1);
+      vaddr[db][u] = key * ROWB + ((chunk ^ kv_swz<HD>(key)) * 16) + 8 * (pc & 1);
+    }
+
+  const int passes = QB == 1 ? 2 : 1;
+  for (int pass = 0; pass < passes; ++pass) {
+    // ---- which query block this wave owns --------------------------------------------------------
+    int blk_q, pair;
+    bool blk_ok;
+    if (QB == 1) {                       // one block at a time: the heavy one of pair blockIdx.x, then the light one
+      pair = blockIdx.x;
+      blk_q = pass == 0 ? nblk - 1 - pair : pair;
+      blk_ok = pair < npair && !(pass == 1 && pair == nblk - 1 - pair);
+    } else {
+      pair = (int)blockIdx.x * (QB >> 1) + (slot >> 1);
+      blk_q = (slot & 1) ? nblk - 1 - pair : pair;
+      blk_ok = pair < npair && !((slot & 1) && pair == nblk - 1 - pair);
+    }
+    const int q0 = blk_q * 32;
+    const bool active = blk_ok && head_ok;
+    // tiles: this wave's, and the work-group's (the heaviest block any of its waves owns)
+    const int p_first = q_pos0 + min(q0, T - 1), p_last = q_pos0 + min(q0 + 31, T - 1);
+    const int nt_wave = active ? p_last / TK + 1 : 0;
+    int wg_pair0 = QB == 1 ? (int)blockIdx.x : (int)blockIdx.x * (QB >> 1);
+    int wg_blk = QB == 1 ? (pass == 0 ? nblk - 1 - wg_pair0 : wg_pair0) : nblk - 1 - wg_pair0;   // heaviest block of the work-group
+    wg_blk = max(min(wg_blk, nblk - 1), 0);
+    const int nt = (q_pos0 + min(wg_blk * 32 + 31, T - 1)) / TK + 1;
+
+    // ---- Q fragments (B operand of S^T): Q[q0 + qq][16 ks + 8 h ..] ---------------------------------
+    const int qi = min(q0 + qq, T - 1);
+    const int qpos = q_pos0 + qi;
+    u32x4_t qf[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      qf[ks] = active ? *reinterpret_cast<const u32x4_t*>(q + ((size_t)qi * nh + head) * HD + ks * 16 + h * 8) : u32x4_t{0, 0, 0, 0};
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_used = -INFINITY, lsum = 0.f;
+
+    auto issue = [&](int t, int st) {
+      unsigned char* base = smem + st * STAGE;
+      int blk[PPW], off[PPW];
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {            // the block ids first (scalar loads, one round trip for all of them)
+        const int k0 = min(t * TK + (wave + NW * i) * KPP, last_piece_key);   // rows past the context: the last piece again (masked by position)
+        int bi;
+        if (bs_shift >= 0) { bi = k0 >> bs_shift; off[i] = k0 & (bs - 1); }
+        else { bi = k0 / bs; off[i] = k0 - bi * bs; }
+        blk[i] = block_table[bi];
+      }
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        const int piece = wave + NW * i;
+        const size_t row = ((size_t)blk[i] * nkv + kvh) * bs + off[i];
+        glds16(kpool + row * HD + dma_lane_off, base + piece * 1024);
+        glds16(vpool + row * HD + dma_lane_off, base + KBYTES + piece * 1024);
+      }
+    };
+
+    int st_issue = 0, st_read = 0;
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    st_issue = 2;
+    // hipcc waits for a plain load at its first use -- inside the tile loop, as vmcnt(0) on every iteration, which would drain
+    // the two tiles in flight each time.  Taking the Q fragments through an empty asm here puts that wait in front of the loop.
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every wave's pieces of tile t are in; everyone is done reading tile t - 1
+      if (t + 2 < nt) {
+        issue(t + 2, st_issue);
+        st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+      }
+      const unsigned char* Kst = smem + st_read * STAGE;
+      const unsigned char* Vst = Kst + KBYTES;
+      st_read = st_read == NSTAGE - 1 ? 0 : st_read + 1;
+      if (t >= nt_wave) continue;                // wave-uniform: the tile lies in this block's future (or the slot is idle)
+
+      // ---- S^T = K . Q^T : two 32-key blocks.  The K fragments of a block are requested one block ahead of the MFMAs
+      // that take them (8 reads in flight; hipcc left to itself issues read -> wait -> MFMA one at a time) ----
+      f32x16_t sc[2];
+      {
+        bf16x8_t kf[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(Kst + kaddr[ks]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks) {
+            sc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], __builtin_bit_cast(bf16x8_t, qf[ks]), sc[b], 0, 0, 0);
+            if (b == 0) kf[ks] = *reinterpret_cast<const bf16x8_t*>(Kst + 32 * ROWB + kaddr[ks]);
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, KSTEPS, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      }
+      // ---- online softmax: this lane holds 32 scores of query qq (keys (r & 3) + 8 (r >> 2) + 4 h of each block) ----
+      const bool need_mask = t * TK + TK - 1 > p_first;
+      if (need_mask) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (t * TK + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h > qpos) sc[b][r] = -INFINITY;
+      }
+      float mx = sc[0][0];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[b][r]);
+      {
+        const f32x2_t sw = swap32_pair(mx);
+        mx = fmaxf(sw[0], sw[1]);
+      }
+      const float ms = mx * scale_log2e;         // key 0 is visible to every query: finite from the first tile on
+      const bool moved = ms > m_used + kDeferLog2;
+      if (__any(moved)) {
+        const float mn = moved ? ms : m_used;
+        const float alpha = moved ? fexp2(m_used - mn) : 1.f;   // exp2(-inf) = 0 on the first tile
+        m_used = mn;
+        lsum *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      // ---- p = exp2(s - m), packed to bf16 = the B operands of O^T += V^T . P^T.  The transposed V fragments of the first
+      // kVAhead MFMAs are requested in front of the exponentials (no dependence), the rest kVAhead MFMAs ahead of their use ----
+      // The transposed reads are inline asm: behind the builtin hipcc assumes the read may alias the LDS-DMAs in flight and
+      // drains them (s_waitcnt vmcnt(0) per tile).  Their completion is counted by hand: LDS reads return in order, and between
+      // the first V read of a tile and its last MFMA the wave issues no other LDS or scalar-memory instruction.
+      constexpr int NPV = 4 * DB;               // MFMAs: (b, s2) outer, d-block inner
+      constexpr int kVAhead = 4;
+      s16x4_t vlo[NPV], vhi[NPV];
+      unsigned vbase[DB][2];
+      const unsigned vst_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Vst;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) { vbase[db][0] = vst_lds + vaddr[db][0]; vbase[db][1] = vst_lds + vaddr[db][1]; }
+#define MI_VREAD(i_)                                                                                                         \
+      do {                                                                                                                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[i_]) : "v"(vbase[(i_) % DB][0]), "n"(16 * ((i_) / DB) * ROWB)); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[i_]) : "v"(vbase[(i_) % DB][1]), "n"(16 * ((i_) / DB) * ROWB)); \
+      } while (0)
+      MI_VREAD(0); MI_VREAD(1); MI_VREAD(2); MI_VREAD(3);
+      static_assert(kVAhead == 4, "the prefetch above is written out for 4");
+      bf16x8_t pb[4];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = fexp2(fmaf(sc[b][r], scale_log2e, -m_used));   // masked: exp2(-inf) = 0
+          lsum += pv[r];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pk.w[k] = pack_bf16x2(pv[8 * s2 + 2 * k], pv[8 * s2 + 2 * k + 1]);
+          pb[2 * b + s2] = pk.v;
+        }
+      }
+      // ---- O^T += V^T . P^T --------------------------------------------------------------------------
+      // before MFMA i: reads issued = 2 min(i + 1 + kVAhead - 1, NPV) ... all but the ones behind fragment i may be outstanding
+#define MI_PV(i_)                                                                                                            \
+      do {                                                                                                                   \
+        constexpr int issued = 2 * ((i_) + kVAhead < NPV ? (i_) + kVAhead : NPV);                                            \
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vlo[i_]), "+v"(vhi[i_]) : "n"(issued - 2 * ((i_) + 1)));               \
+        const s16x4_t lo = vlo[i_], hi = vhi[i_];                                                                            \
+        const bf16x8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                         \
+        o[(i_) % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[(i_) / DB], o[(i_) % DB], 0, 0, 0);                     \
+        if constexpr ((i_) + kVAhead < NPV) MI_VREAD((i_) + kVAhead);                                                        \
+      } while (0)
+      MI_PV(0); MI_PV(1); MI_PV(2); MI_PV(3); MI_PV(4); MI_PV(5); MI_PV(6); MI_PV(7);
+      if constexpr (NPV == 16) { MI_PV(8); MI_PV(9); MI_PV(10); MI_PV(11); MI_PV(12); MI_PV(13); MI_PV(14); MI_PV(15); }
+#undef MI_PV
+#undef MI_VREAD
+    }
+    // ---- epilogue: O^T[d][q] / l -> out[q][head][d]; lanes l and l + 32 hold neighbouring 4-dim groups of one query:
+    // one v_permlane32_swap per pair of groups makes 16-byte stores of them
+    {
+      const f32x2_t sw = swap32_pair(lsum);
+      lsum = sw[0] + sw[1];
+    }
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const bool st_ok = active && q0 + qq < T;
+    uint16_t* orow = out + ((size_t)(q0 + qq) * nh + head) * HD;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int k2 = 0; k2 < 4; k2 += 2) {      // dim groups k2, k2 + 1: dims 32 db + 8 k + 4 h + (0..3)
+        uint32_t a0 = pack_bf16x2(o[db][4 * k2 + 0] * inv, o[db][4 * k2 + 1] * inv);
+        uint32_t a1 = pack_bf16x2(o[db][4 * k2 + 2] * inv, o[db][4 * k2 + 3] * inv);
+        uint32_t b0 = pack_bf16x2(o[db][4 * k2 + 4] * inv, o[db][4 * k2 + 5] * inv);
+        uint32_t b1 = pack_bf16x2(o[db][4 * k2 + 6] * inv, o[db][4 * k2 + 7] * inv);
+        const auto x = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // lower half: [own group k2 | upper's group k2] = dims 8 k2 .. 8 k2 + 7; upper half: [lower's k2 + 1 | own k2 + 1]
+        const u32x4_t v = {x[0], y[0], x[1], y[1]};
+        if (st_ok) *reinterpret_cast<u32x4_t*>(orow + 32 * db + 8 * (k2 + h)) = v;
+      }
+    __syncthreads();   // the ring is reused by the next pass
+  }
+}
+
+static bool attn_prefill_v1() {   // MI355X_ATTN_PREFILL_V1=1: the first-generation kernel (A/B)
+  static const bool on = [] { const char* v = getenv("MI355X_ATTN_PREFILL_V1"); return v && v[0] == '1'; }();
+  return on;
+}
+
 int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kpool, const uint16_t* vpool,
                         int block_size, const int32_t* block_table, int nh, int nkv, int hd, uint16_t* out,
                         hipStream_t s) {
@@ -685,8 +1018,28 @@ int launch_attn_prefill(const uint16_t* q, int T, int q_pos0, const uint16_t* kp
   MI_CHECK(ceil_div(q_pos0 + T, block_size) <= kPrefillMaxBlocks, "attention: context spans more than 4096 blocks");
   const int G = nh / nkv;
   const int Gp = G <= 1 ? 1 : (G <= 2 ? 2 : (G <= 4 ? 4 : 8));
-  const int waves = Gp < 4 ? 4 : Gp, QB = waves / Gp;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
+  if (!attn_prefill_v1()) {
+    // second generation: 8 waves = (8 / Gp) query blocks x Gp heads; blocks in complementary pairs
+    const int nblk = ceil_div(T, 32), npair = (nblk + 1) / 2, qb = 8 / Gp;
+    int bs_shift = -1;
+    for (int sh = 4; sh < 20; ++sh) if ((1 << sh) == block_size) bs_shift = sh;
+    const dim3 grid2(ceil_div(npair, qb >= 2 ? qb / 2 : 1), nkv);
+    if (hd == 128) {
+      constexpr int lds = 3 * 2 * 64 * 256;
+      MI_TRY_A(ensure_dynamic_lds(reinterpret_cast<const void*>(attn_prefill2_kernel<128, 8>), lds));
+      hipLaunchKernelGGL((attn_prefill2_kernel<128, 8>), grid2, dim3(512), lds, s, q, T, q_pos0, kpool, vpool, block_size, bs_shift,
+                         block_table, nh, nkv, G, Gp, nblk, out, scale_log2e);
+    } else {
+      constexpr int lds = 3 * 2 * 64 * 128;
+      MI_TRY_A(ensure_dynamic_lds(reinterpret_cast<const void*>(attn_prefill2_kernel<64, 8>), lds));
+      hipLaunchKernelGGL((attn_prefill2_kernel<64, 8>), grid2, dim3(512), lds, s, q, T, q_pos0, kpool, vpool, block_size, bs_shift,
+                         block_table, nh, nkv, G, Gp, nblk, out, scale_log2e);
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
+  const int waves = Gp < 4 ? 4 : Gp, QB = waves / Gp;
   const int nqb = ceil_div(T, 32 * QB);
   const int paired = nqb * nkv > 384 ? 1 : 0;   // more blocks than 1.5 per CU: pair complementary ones
   const dim3 grid(paired ? ceil_div(nqb, 2) : nqb, nkv);
