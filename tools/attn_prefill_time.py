@@ -6,8 +6,11 @@ import torch
 from vllm_neuron_amd import _native as lib
 L = lib.load_library()
 nh, nkv, hd, bs = 32, 8, 128, 32
-for T in (239, 495, 1007, 2031):
-    MB = (T + bs - 1) // bs + 1
+cases = [(239, 0), (495, 0), (1007, 0), (2031, 0)]
+if len(sys.argv) > 1:   # T:pos0 pairs
+    cases = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]]
+for T, pos0 in cases:
+    MB = (pos0 + T + bs - 1) // bs + 1
     nb = 1 + MB
     pool = torch.randn(2, nb, nkv, bs, hd, device="cuda").to(torch.bfloat16)
     bt = torch.zeros(MB, dtype=torch.int32)
@@ -16,7 +19,7 @@ for T in (239, 495, 1007, 2031):
     q = torch.randn(T, nh, hd, device="cuda").to(torch.bfloat16)
     out = torch.empty(T, nh * hd, dtype=torch.bfloat16, device="cuda")
     def launch():
-        lib.check(L.mi_op_paged_attn_prefill(q.data_ptr(), T, 0, pool.data_ptr(), nb, bs, btd.data_ptr(), MB, nh, nkv, hd,
+        lib.check(L.mi_op_paged_attn_prefill(q.data_ptr(), T, pos0, pool.data_ptr(), nb, bs, btd.data_ptr(), MB, nh, nkv, hd,
                                              out.data_ptr(), None))
     for _ in range(5): launch()
     torch.cuda.synchronize()
@@ -26,5 +29,5 @@ for T in (239, 495, 1007, 2031):
     for _ in range(reps): launch()
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / reps
-    fl = 4 * nh * hd * T * T / 2
-    print(f"T={T}: {us:.1f} us  {fl / us / 1e9:.3f} PF/s  (v1={os.environ.get('MI355X_ATTN_PREFILL_V1', '0')})", flush=True)
+    fl = 4 * nh * hd * (T * T / 2 + T * pos0)
+    print(f"T={T} pos0={pos0}: {us:.1f} us  {fl / us / 1e9:.3f} PF/s  (v1={os.environ.get('MI355X_ATTN_PREFILL_V1', '0')})", flush=True)

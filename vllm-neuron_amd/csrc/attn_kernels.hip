@@ -828,29 +828,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m_used = -INFINITY, lsum = 0.f;
 
-    auto issue = [&](int t, int st) {
-      unsigned char* base = smem + st * STAGE;
-      int blk[PPW], off[PPW];
+    // Block ids are fetched (scalar loads) one tile ahead of the DMAs that use them: the round trip to the scalar cache / L2
+    // runs under a tile's arithmetic instead of in front of the global_load_lds it feeds.
+    int pf_blk[PPW], pf_off[PPW];
+    auto fetch_ids = [&](int t) {
 #pragma unroll
-      for (int i = 0; i < PPW; ++i) {            // the block ids first (scalar loads, one round trip for all of them)
+      for (int i = 0; i < PPW; ++i) {
         const int k0 = min(t * TK + (wave + NW * i) * KPP, last_piece_key);   // rows past the context: the last piece again (masked by position)
         int bi;
-        if (bs_shift >= 0) { bi = k0 >> bs_shift; off[i] = k0 & (bs - 1); }
-        else { bi = k0 / bs; off[i] = k0 - bi * bs; }
-        blk[i] = block_table[bi];
+        if (bs_shift >= 0) { bi = k0 >> bs_shift; pf_off[i] = k0 & (bs - 1); }
+        else { bi = k0 / bs; pf_off[i] = k0 - bi * bs; }
+        pf_blk[i] = block_table[bi];
       }
+    };
+    auto issue = [&](int st) {                  // the tile whose ids fetch_ids loaded last
+      unsigned char* base = smem + st * STAGE;
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
         const int piece = wave + NW * i;
-        const size_t row = ((size_t)blk[i] * nkv + kvh) * bs + off[i];
+        const size_t row = ((size_t)pf_blk[i] * nkv + kvh) * bs + pf_off[i];
         glds16(kpool + row * HD + dma_lane_off, base + piece * 1024);
         glds16(vpool + row * HD + dma_lane_off, base + KBYTES + piece * 1024);
       }
     };
 
     int st_issue = 0, st_read = 0;
-    issue(0, 0);
-    if (nt > 1) issue(1, 1);
+    fetch_ids(0);
+    issue(0);
+    if (nt > 1) { fetch_ids(1); issue(1); }
+    fetch_ids(2);
     st_issue = 2;
     // hipcc waits for a plain load at its first use -- inside the tile loop, as vmcnt(0) on every iteration, which would drain
     // the two tiles in flight each time.  Taking the Q fragments through an empty asm here puts that wait in front of the loop.
@@ -861,8 +867,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();            // every wave's pieces of tile t are in; everyone is done reading tile t - 1
       if (t + 2 < nt) {
-        issue(t + 2, st_issue);
+        issue(st_issue);
         st_issue = st_issue == NSTAGE - 1 ? 0 : st_issue + 1;
+        fetch_ids(t + 3);
       }
       const unsigned char* Kst = smem + st_read * STAGE;
       const unsigned char* Vst = Kst + KBYTES;
