@@ -94,7 +94,7 @@ typedef struct mi_model_config {
 enum { MI_TP_TRANSPORT_P2P = 0, MI_TP_TRANSPORT_RCCL = 1 };
 
 const char* mi_last_error(void);
-int mi_version(void);   /* 3 = this header; 2 lacked tp_device_ids / tp_transport / MI_TP_ALL_RANKS; 1 lacked mi_forward_tokens, mi_op_sample, mi_tp_init_transport */
+int mi_version(void);   /* 4 = this header (+ mi_tp_plan, mi_tp_info); 3 lacked them; 2 lacked tp_device_ids / tp_transport / MI_TP_ALL_RANKS; 1 lacked mi_forward_tokens, mi_op_sample, mi_tp_init_transport */
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out);
 int mi_ctx_destroy(mi_ctx* ctx);
@@ -247,6 +247,35 @@ int mi_tp_init(mi_ctx* ctx, const void* id128);
 typedef int (*mi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
 typedef int (*mi_allgather_fn)(void* user, const void* send, void* recv, size_t count, void* stream);
 int mi_tp_init_transport(mi_ctx* ctx, mi_allreduce_fn all_reduce, mi_allgather_fn all_gather, void* user);
+
+/* The sharding plan of rank `rank` of cfg->tp_degree: which slices of the UNSHARDED checkpoint tensors the rank holds
+ * (tp_degree = tensor_parallel_size, loader.py:752-753; head counts that do not divide are allowed, the reference skips
+ * vLLM's divisibility check at platform.py:58-64).  Host only: no device, no context -- the same function mi_ctx_create
+ * runs.  q heads [q_head0, q_head0 + q_heads_real) are real; the rank computes q_heads_local >= q_heads_real heads, the
+ * surplus being zero-weight padding heads (q rows, q bias and o_proj columns zero).  kv heads [kv_head0, + kv_heads_local);
+ * gate / up rows and down_proj columns [inter0, + inter_local); lm_head rows (logit columns) [vocab0, + vocab_local). */
+typedef struct mi_tp_plan {
+  int32_t q_head0, q_heads_real, q_heads_local;
+  int32_t kv_head0, kv_heads_local;
+  int32_t inter0, inter_local;
+  int32_t vocab0, vocab_local;
+} mi_tp_plan_t;
+int mi_tp_plan(const mi_model_config* cfg, int32_t rank, mi_tp_plan_t* out);
+
+/* What an in-process tensor-parallel context (tp_rank = MI_TP_ALL_RANKS, finalized) actually runs on -- so that a benchmark
+ * record can tell "N ranks over peer memory, in hipGraphs" from "fell back to RCCL, eager". */
+typedef struct mi_tp_info {
+  int32_t tp_degree;
+  int32_t transport;       /* MI_TP_TRANSPORT_* in use after the self-test */
+  int32_t selftest;        /* 1: passed on the transport in use; -1: the peer-memory exchange failed it (transport is RCCL now); 0: not run */
+  int32_t graphs;          /* 1: token-generation steps, exchange kernels included, replay from a hipGraph per shard */
+  int32_t mode;            /* 0: one GPU per rank; 1: every shard on one GPU in lockstep (one stream, host barriers between the
+                              exchange kernels); 2: every shard on one GPU, one stream per shard, the kernels wait on device flags */
+  int32_t timeout_ms;      /* bound of a flag wait; on expiry the output is poisoned with NaN and MI_ECOMM is reported */
+  int32_t device_ids[16];
+  int32_t peer_access[16]; /* bit p of word r: rank r's device maps rank p's memory */
+} mi_tp_info_t;
+int mi_tp_info(mi_ctx* ctx, mi_tp_info_t* out);
 
 /* ---- per-kernel entry points (device pointers; stream may be NULL) -------------------- */
 

@@ -63,13 +63,13 @@ def test_quantize_bit_exact(lib, wd, qt):
 
 
 @pytest.mark.parametrize("wd", ["f8e4m3", "int8", "bf16"])
-@pytest.mark.parametrize("M,path", [(1, 1), (4, 1), (16, 1), (4, 2), (17, 2), (200, 2), (256, 2),
-                                    (17, 3), (200, 3), (300, 3)])     # 3 = the wide-N LDS-DMA GEMM
+@pytest.mark.parametrize("M,path", [(1, 1), (4, 1), (16, 1), (17, 1), (24, 1), (32, 1), (4, 2), (17, 2), (200, 2), (256, 2),
+                                    (17, 3), (200, 3), (300, 3)])     # 3 = the wide-N LDS-DMA GEMM; (17 .. 32, 1): two 16-column groups per weight stream
 @pytest.mark.parametrize("N,K", [(576, 448), (1024, 4096), (256, 14336), (3584, 18944), (272, 28672)])
 def test_qlinear(lib, wd, M, path, N, K):
     """(16, 14336), (4 / 16, 18944) and (* , 28672) on the GEMV path do not fit in LDS whole: they
     run the K-streamed weight-streaming kernel (gemv_kstream_kernel; Qwen2.5-7B / Llama-3.3-70B down_proj shapes)."""
-    if K > 16384 and (path >= 2 or wd == "bf16") and M not in (4, 17):
+    if K > 16384 and (path >= 2 or wd == "bf16") and M not in (4, 17, 32):
         pytest.skip("big-K shapes: one GEMM and one bf16 case are enough")
     if path == 3 and wd == "bf16":
         pytest.skip("the wide-N GEMM takes 1-byte weights")
@@ -96,7 +96,8 @@ def test_qlinear(lib, wd, M, path, N, K):
 
 @pytest.mark.parametrize("wd", ["f8e4m3", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(3, 272, 28672), (5, 272, 28672), (8, 528, 28672), (9, 272, 28672), (13, 272, 28672),
-                                   (16, 4096, 28672), (4, 3584, 18944), (7, 272, 18944), (6, 272, 14336), (16, 4096, 14336)])
+                                   (16, 4096, 28672), (4, 3584, 18944), (7, 272, 18944), (6, 272, 14336), (16, 4096, 14336),
+                                   (17, 272, 14336), (29, 528, 18944), (32, 4096, 14336), (32, 272, 28672), (20, 272, 4096)])
 def test_qlinear_activations_streamed_beside_the_weights(lib, wd, M, N, K):
     """bf16 activations too large for the LDS (rows x K): gemv_kstream_kernel stages each wave's K-slice
     by LDS-DMA, 16 / 8 / 4 k-tiles per sub-chunk for up to 4 / 8 / 16 rows; ragged K-slices

@@ -97,8 +97,9 @@ def test_random_call_sequences_match_oracle(seed):
 @pytest.mark.parametrize("name,wd", [("llama31_like", "f8e4m3"), ("qwen25_like", "int8"), ("tinyllama_like", "bf16")])
 def test_wide_decode_batches_match_oracle(name, wd):
     """Token-generation batches of 5..16 rows (the GEMV's general staging path: more than four
-    rows per norm prologue) and of 17..32 rows (the platform's default max_num_seqs is 32: those
-    batches take the context-encoding GEMMs) against the oracle."""
+    rows per norm prologue) and of 17..32 rows (the platform's default max_num_seqs is 32: two
+    16-column MFMA groups per wave over one weight stream -- gemv_bigk_kernel<MG = 2> for the norm
+    prologues, gemv_kstream_kernel<MG = 2> for the bf16 activations) against the oracle."""
     bs, maxlen, nseq = 32, 256, 32
     mb = maxlen // bs
     nb = 1 + nseq * mb

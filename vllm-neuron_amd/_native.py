@@ -53,6 +53,17 @@ class MiKvStats(C.Structure):
                 ("block_table_rows_sent", C.c_int64), ("block_table_rows_kept", C.c_int64)]
 
 
+class MiTpPlan(C.Structure):
+    _fields_ = [("q_head0", C.c_int32), ("q_heads_real", C.c_int32), ("q_heads_local", C.c_int32),
+                ("kv_head0", C.c_int32), ("kv_heads_local", C.c_int32), ("inter0", C.c_int32), ("inter_local", C.c_int32),
+                ("vocab0", C.c_int32), ("vocab_local", C.c_int32)]
+
+
+class MiTpInfo(C.Structure):
+    _fields_ = [("tp_degree", C.c_int32), ("transport", C.c_int32), ("selftest", C.c_int32), ("graphs", C.c_int32),
+                ("mode", C.c_int32), ("timeout_ms", C.c_int32), ("device_ids", C.c_int32 * 16), ("peer_access", C.c_int32 * 16)]
+
+
 # include/mi355x_vllm.h: mi_allreduce_fn / mi_allgather_fn
 MI_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 MI_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -91,6 +102,8 @@ _SIGS = {
     "mi_tp_unique_id": (C.c_int, [C.c_void_p]),
     "mi_tp_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mi_tp_init_transport": (C.c_int, [C.c_void_p, MI_ALLREDUCE_FN, MI_ALLGATHER_FN, C.c_void_p]),
+    "mi_tp_plan": (C.c_int, [C.POINTER(MiModelConfig), C.c_int32, C.POINTER(MiTpPlan)]),
+    "mi_tp_info": (C.c_int, [C.c_void_p, C.POINTER(MiTpInfo)]),
     "mi_op_tp_all_reduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "mi_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

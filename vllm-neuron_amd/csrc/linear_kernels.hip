@@ -196,8 +196,9 @@ size_t gemv_lds_bytes(int M, int K) {
 }
 // every M <= 16 streams the weights: images that do not fit in LDS whole are staged in K-chunks
 // (gemv_bigk_kernel)
-bool gemv_fits(int M, int K) { (void)K; return M <= 16; }
-static bool gemv_fits_whole(int M, int K) { return gemv_lds_bytes(M, K) <= 160 * 1024; }
+bool gemv_fits(int M, int K) { (void)K; return M <= 32; }
+// the whole-image kernels multiply one 16-column MFMA group
+static bool gemv_fits_whole(int M, int K) { return M <= 16 && gemv_lds_bytes(M, K) <= 160 * 1024; }
 
 // position (in 16-byte units) of the 8-element chunk c8 of row m in the fragment image
 template <int WD>
@@ -963,11 +964,12 @@ static int launch_gemv_t(const LinearW& w, int M, const ProArgs& p, const EpiArg
 // are staged between two barriers while the next chunk's first weight batches are already in
 // flight.  The K-slices are combined in wave order (deterministic).
 // LDS: [x chunk: CKT k-tiles][zero slot][red: 8 waves x 64 lanes x 16 B][scale 16][bias 16][ssq 16 x 16]
-static size_t gemv_bigk_fixed_lds() { return 16 + kGemvWaves * 64 * 16 + 2 * 16 * 4 + 16 * 16 * 4; }
+// (17 .. 32 rows: two 16-column MFMA groups per wave share one weight stream -- MG = 2: twice the K-slice reduction buffer, 32 rows of sums of squares)
+static size_t gemv_bigk_fixed_lds(int mg) { return 16 + (size_t)mg * kGemvWaves * 64 * 16 + 2 * kGemvWaves * 16 * 4 + (size_t)mg * 16 * 16 * 4; }
 static int gemv_bigk_chunk_kt(int M, int K, int wd) {
   const int KT = K / tile_k(wd);
   const size_t per_kt = (size_t)M * tile_k(wd) * 2;
-  const int cap = (int)((160 * 1024 - gemv_bigk_fixed_lds()) / per_kt);
+  const int cap = (int)((160 * 1024 - gemv_bigk_fixed_lds(M > 16 ? 2 : 1)) / per_kt);
   const int NC = ceil_div(KT, cap);
   return min(cap, ceil_div(ceil_div(KT, NC), kGemvWaves) * kGemvWaves);   // equal slices for the 8 waves
 }
@@ -1035,45 +1037,120 @@ __device__ __forceinline__ void gemv_stage_chunk(const ProArgs& p, int M, int K,
   }
 }
 
-template <int WD, int PRO, int EPI>
+// KS waves split the K dimension of ONE row-tile and a work-group walks TP = 8 / KS ... row-tiles side by side, all of them
+// against the SAME staged activation chunk (gemv_kernel's decomposition): with 17 .. 32 rows the activations are the larger
+// operand -- 32 rows x 4096 fp32 residuals = 512 KiB per work-group and pass against 64 KiB of weights per row-tile -- so
+// they must cross the chip once per work-group, not once per row-tile.  MG = 2: two 16-column MFMA groups (rows 0..15,
+// 16..31) per wave over one weight stream, the weight fragment decoded once.  KS = 8, TP = 1, MG = 1 is the original form.
+// The same staging for MANY rows (17 .. 32).  gemv_stage_chunk walks the rows four at a time with one dependent trip to
+// L2 per step -- 8 steps x 2 chunks at 32 rows, ~25 us of a 35 us QKV launch.  Here a wave owns rows wave, wave + 8, ...
+// whole (its lanes cover the chunk's columns, kRowJ 16-byte groups each), two rows in flight, and leaves the row's sum of
+// squares in its own slot of ssq (the other waves' slots stay zero: gemv_row_rinv adds all eight).
+constexpr int kRowJ = 4;   // 8-element column groups per lane and row: chunks of up to 64 * 4 * 8 = 2048 columns
+template <int WD, int PRO>
+__device__ __forceinline__ void gemv_stage_chunk_rows(const ProArgs& p, int M, int K, int k0, int ck, uint4* xf, float* ssq,
+                                                      bool first_chunk, bool take_ssq, bool store_resid) {
+  static_assert(PRO != PRO_BF16, "norm prologues");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nch = ck >> 3, c0 = k0 >> 3;
+  float g[kRowJ][8];
+#pragma unroll
+  for (int j = 0; j < kRowJ; ++j) load8(p.gain + (size_t)(c0 + min(lane + 64 * j, nch - 1)) * 8, g[j]);
+  float hA[kRowJ][8], hB[kRowJ][8];
+  auto load_row = [&](float (&h)[kRowJ][8], int m) {
+    const int mm = min(m, M - 1);
+#pragma unroll
+    for (int j = 0; j < kRowJ; ++j) {
+      const size_t at = (size_t)mm * K + (size_t)(c0 + min(lane + 64 * j, nch - 1)) * 8;
+      load8(p.resid_in + at, h[j]);
+      if constexpr (PRO == PRO_NORM_PARTIAL) {
+        float pv[8];
+        load8(p.partial + at, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[j][e] += pv[e];
+      }
+    }
+  };
+  auto emit_row = [&](float (&h)[kRowJ][8], int m) {
+    if (m >= M) return;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kRowJ; ++j) {
+      const int c8 = lane + 64 * j;
+      if (c8 < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(h[j][e], h[j][e], ss);
+        if (store_resid && p.resid_out) {
+          float* o = p.resid_out + (size_t)m * K + (size_t)(c0 + c8) * 8;
+          *reinterpret_cast<float4*>(o) = make_float4(h[j][0], h[j][1], h[j][2], h[j][3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(h[j][4], h[j][5], h[j][6], h[j][7]);
+        }
+        uint4 o4;
+        o4.x = pack_bf16x2(h[j][0] * g[j][0], h[j][1] * g[j][1]);
+        o4.y = pack_bf16x2(h[j][2] * g[j][2], h[j][3] * g[j][3]);
+        o4.z = pack_bf16x2(h[j][4] * g[j][4], h[j][5] * g[j][5]);
+        o4.w = pack_bf16x2(h[j][6] * g[j][6], h[j][7] * g[j][7]);
+        xf[xfrag_slot<WD>(c8, m, M)] = o4;
+      }
+    }
+    if (take_ssq) {
+      const float t = wave_sum(ss);
+      if (lane == 0) ssq[m * 16 + wave] = first_chunk ? t : ssq[m * 16 + wave] + t;
+    }
+  };
+  load_row(hA, wave);
+  for (int m = wave; m < M; m += 2 * kGemvWaves) {
+    load_row(hB, m + kGemvWaves);
+    emit_row(hA, m);
+    load_row(hA, m + 2 * kGemvWaves);
+    emit_row(hB, m + kGemvWaves);
+  }
+}
+
+template <int WD, int PRO, int EPI, int MG = 1, int KS = kGemvWaves>
 __global__ __launch_bounds__(kGemvWaves * 64) void gemv_bigk_kernel(const uint4* __restrict__ W, int NT, int KT, int M,
-                                                                    int K, int CKT, ProArgs p, EpiArgs e) {
+                                                                    int K, int CKT, int TP, ProArgs p, EpiArgs e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TK = (WD == MI_W_BF16) ? 32 : 64;
   uint4* xf = reinterpret_cast<uint4*>(smem);
   const int zero_slot = (M * CKT * TK) >> 3;
   unsigned char* tail = smem + (size_t)M * CKT * TK * 2 + 16;
-  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);
-  float* sc_lds = reinterpret_cast<float*>(tail + kGemvWaves * 64 * 16);
-  float* bi_lds = sc_lds + 16;
-  float* ssq_lds = bi_lds + 16;
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);                     // [MG][8 waves][64 lanes]
+  float* sc_lds = reinterpret_cast<float*>(tail + MG * kGemvWaves * 64 * 16);   // [8 row-tiles][16]
+  float* bi_lds = sc_lds + kGemvWaves * 16;
+  float* ssq_lds = bi_lds + kGemvWaves * 16;                           // [16 MG rows][16 waves]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const bool col_ok = c < M;
+  const int tsub = wave / KS, kslice = wave % KS;
+  const bool wave_on = tsub < TP;                                      // waves beyond KS * TP only stage activations
+  bool col_ok[MG];                                                     // column c of group q = activation row 16 q + c
+#pragma unroll
+  for (int q = 0; q < MG; ++q) col_ok[q] = 16 * q + c < M;
   const int NC = ceil_div(KT, CKT);
-  const int ktw = ceil_div(CKT, kGemvWaves);          // k-tiles of a chunk per wave
-  const int nb = ceil_div(ktw, kGemvU);               // batches per (tile, chunk), same for every wave
-  const int my_tiles = (int)blockIdx.x < NT ? ceil_div(NT - (int)blockIdx.x, (int)gridDim.x) : 0;
-  const int total = my_tiles * NC * nb;
+  const int ktw = ceil_div(CKT, KS);                  // k-tiles of a chunk per wave
+  const int nb = ceil_div(ktw, kGemvU);               // batches per (pass, chunk), same for every wave
+  const int units = ceil_div(NT, TP);                 // a pass = TP row-tiles
+  const int my_units = (int)blockIdx.x < units ? ceil_div(units - (int)blockIdx.x, (int)gridDim.x) : 0;
+  const int total = my_units * NC * nb;
 
-  // sequence index -> (tile, chunk, batch); the slice of wave w inside chunk ch is
-  // [ch * CKT + w * ktw, ... + ktw) clipped to the chunk and to KT
+  // sequence index -> (pass, chunk, batch); the slice of K-slice ks inside chunk ch is
+  // [ch * CKT + ks * ktw, ... + ktw) clipped to the chunk and to KT
   auto slice = [&](int ch, int& kbeg, int& kend) {
     const int cend = min((ch + 1) * CKT, KT);
-    kbeg = min(ch * CKT + wave * ktw, cend);
+    kbeg = min(ch * CKT + kslice * ktw, cend);
     kend = min(kbeg + ktw, cend);
   };
   u32x4_t bufA[kGemvU], bufB[kGemvU];
   auto issue = [&](u32x4_t (&buf)[kGemvU], int i) {
-    const bool live = i < total;
+    const bool live = i < total && wave_on;
     i = min(i, max(total - 1, 0));
     const int it = i / (NC * nb), rem = i - it * NC * nb, ch = rem / nb, b = rem - ch * nb;
     int kbeg, kend;
     slice(ch, kbeg, kend);
-    const int tile = min((int)blockIdx.x + it * (int)gridDim.x, NT - 1);
+    const int tile_raw = ((int)blockIdx.x + it * (int)gridDim.x) * TP + tsub;
+    const int tile = min(tile_raw, NT - 1);
     const int klast = max(kend - 1, kbeg);
-    const bool any = live && kbeg < kend;
+    const bool any = live && kbeg < kend && tile_raw < NT;
     const uint4* base = any ? W + (size_t)tile * KT * 64 + lane : W;
     const size_t kstep = any ? 64 : 0;
 #pragma unroll
@@ -1081,57 +1158,89 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_bigk_kernel(const uint4*
   };
 
   if (tid == 0) xf[zero_slot] = make_uint4(0, 0, 0, 0);
+  if constexpr (MG > 1 && PRO != PRO_BF16) {   // (row-wise staging fills one wave's slot per row; the first staging barrier orders this)
+    for (int i = tid; i < MG * 16 * 16; i += blockDim.x) ssq_lds[i] = 0.f;
+  }
   issue(bufA, 0);
   issue(bufB, 1);
 
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[MG];
+#pragma unroll
+  for (int q = 0; q < MG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   auto process = [&](u32x4_t (&buf)[kGemvU], int i) {
     const int it = i / (NC * nb), rem = i - it * NC * nb, ch = rem / nb, b = rem - ch * nb;
     int kbeg, kend;
     slice(ch, kbeg, kend);
+    const int tile0 = ((int)blockIdx.x + it * (int)gridDim.x) * TP;    // first row-tile of the pass
     if (b == 0) {   // a new chunk: every wave is done with the previous image
       __syncthreads();
-      if (ch == 0 && tid < 16) {
-        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-        sc_lds[tid] = e.scale[tile * 16 + tid];
-        bi_lds[tid] = e.bias ? e.bias[tile * 16 + tid] : 0.f;
+      if (ch == 0 && tid < 16 * TP) {
+        const int tile = min(tile0 + (tid >> 4), NT - 1);
+        sc_lds[tid] = e.scale[tile * 16 + (tid & 15)];
+        bi_lds[tid] = e.bias ? e.bias[tile * 16 + (tid & 15)] : 0.f;
       }
       const int k0 = ch * CKT * TK, ck = (min((ch + 1) * CKT, KT) - ch * CKT) * TK;
-      gemv_stage_chunk<WD, PRO>(p, M, K, k0, ck, xf, ssq_lds, ch == 0, it == 0, it == 0 && blockIdx.x == 0);
+      if constexpr (MG > 1 && PRO != PRO_BF16) {
+        if (ck <= 64 * kRowJ * 8) gemv_stage_chunk_rows<WD, PRO>(p, M, K, k0, ck, xf, ssq_lds, ch == 0, it == 0, it == 0 && blockIdx.x == 0);
+        else gemv_stage_chunk<WD, PRO>(p, M, K, k0, ck, xf, ssq_lds, ch == 0, it == 0, it == 0 && blockIdx.x == 0);
+      } else {
+        gemv_stage_chunk<WD, PRO>(p, M, K, k0, ck, xf, ssq_lds, ch == 0, it == 0, it == 0 && blockIdx.x == 0);
+      }
       __syncthreads();
     }
     const int kl0 = kbeg - ch * CKT + b * kGemvU;     // k-tile index inside the chunk image
 #pragma unroll
     for (int u = 0; u < kGemvU; ++u) {
       const int kt = kl0 + u;
-      const bool ok = col_ok && (ch * CKT + kt) < kend;
+      const bool live = (ch * CKT + kt) < kend;
       const u32x4_t w = buf[u];
       if constexpr (WD == MI_W_BF16) {
-        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, xf[ok ? (kt * 4 + g) * M + c : zero_slot]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), bb, acc, 0, 0, 0);
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+          const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, xf[live && col_ok[q] ? (kt * 4 + g) * M + 16 * q + c : zero_slot]);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[q], 0, 0, 0);
+        }
       } else {
-        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 0) * 4 + g) * M + c : zero_slot]);
-        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 1) * 4 + g) * M + c : zero_slot]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
+        const bf16x8_t a0 = decode8<WD>(w[0], w[1]), a1 = decode8<WD>(w[2], w[3]);   // decoded once for all column groups
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+          const bool ok = live && col_ok[q];
+          const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 0) * 4 + g) * M + 16 * q + c : zero_slot]);
+          const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, xf[ok ? ((kt * 2 + 1) * 4 + g) * M + 16 * q + c : zero_slot]);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[q], 0, 0, 0);
+        }
       }
     }
-    if (ch == NC - 1 && b == nb - 1) {   // row-tile done: combine the K-slices in wave order
-      red[wave * 64 + lane] = acc;
-      __syncthreads();
-      if (wave == 0 && col_ok) {
-        f32x4_t s = red[lane];
+    if (ch == NC - 1 && b == nb - 1) {   // the pass's row-tiles are done: combine the K-slices in slice order
+      if constexpr (KS > 1) {
 #pragma unroll
-        for (int w = 1; w < kGemvWaves; ++w) {
-          const f32x4_t t = red[w * 64 + lane];
-          s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
-        }
-        float rmul = 1.f;
-        if constexpr (PRO != PRO_BF16) rmul = gemv_row_rinv(ssq_lds, c, K, p.eps);
-        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
-        epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc_lds + g * 4, e.bias ? bi_lds + g * 4 : nullptr, s, rmul);
+        for (int q = 0; q < MG; ++q) red[(q * kGemvWaves + wave) * 64 + lane] = acc[q];
+        __syncthreads();                 // (the next write to `red` comes behind the staging barriers of the next pass)
       }
-      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int tile = tile0 + tsub;
+      if (kslice == 0 && wave_on && tile < NT) {   // the first wave of a row-tile finishes all its column groups
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+          if (!col_ok[q]) continue;
+          f32x4_t sum = acc[q];
+          if constexpr (KS > 1) {
+            sum = red[(q * kGemvWaves + wave) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < KS; ++w) {
+              const f32x4_t t = red[(q * kGemvWaves + wave + w) * 64 + lane];
+              sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+            }
+          }
+          float rmul = 1.f;
+          if constexpr (PRO != PRO_BF16) rmul = gemv_row_rinv(ssq_lds, 16 * q + c, K, p.eps);
+          epilogue_lds<EPI>(e, 16 * q + c, tile * 16 + g * 4, sc_lds + tsub * 16 + g * 4, e.bias ? bi_lds + tsub * 16 + g * 4 : nullptr,
+                            sum, rmul);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < MG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   };
   for (int i = 0; i < total; i += 2) {
@@ -1159,9 +1268,10 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_bigk_kernel(const uint4*
 // the products differ from it only in the association of the per-wave partial sums (none: each wave
 // still adds its k-tiles in order, the waves are combined in wave order).
 constexpr int kKsBuf = 8 * 1024;                   // bytes of one wave-private activation buffer (<= 8 DMA instructions)
-static size_t gemv_kstream_lds() { return (size_t)kGemvWaves * 2 * kKsBuf + 2 * kGemvWaves * 64 * 16 + 64 * 4 + 16; }
+// reduction buffer: [2 parities][MG column groups][waves 1..7][64 lanes] (wave 0 finishes every group from its own registers)
+static size_t gemv_kstream_lds(int mg) { return (size_t)kGemvWaves * 2 * kKsBuf + (size_t)2 * mg * (kGemvWaves - 1) * 64 * 16 + 64 * 4 + 16; }
 
-template <int WD, int EPI, int U, int kKsDma>   // U k-tiles and kKsDma DMA instructions (64 slots each) per sub-chunk
+template <int WD, int EPI, int U, int kKsDma, int MG = 1>   // U k-tiles and kKsDma DMA instructions (64 slots each) per sub-chunk; MG 16-column groups
 __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uint4* __restrict__ W, int NT, int KT, int M,
                                                                        int K, int G, ProArgs p, EpiArgs e) {
   constexpr int TK = (WD == MI_W_BF16) ? 32 : 64;
@@ -1169,11 +1279,14 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uin
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const bool col_ok = c < M;
+  bool col_ok[MG];                                                       // column c of group q = activation row 16 q + c
+#pragma unroll
+  for (int q = 0; q < MG; ++q) col_ok[q] = 16 * q + c < M;
   unsigned char* xb = smem + (size_t)wave * 2 * kKsBuf;
   unsigned char* tail = smem + (size_t)kGemvWaves * 2 * kKsBuf;
-  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);                       // [2 parities][8 waves][64 lanes]
-  float* sc_lds = reinterpret_cast<float*>(tail + 2 * kGemvWaves * 64 * 16);   // [2 parities][scale 16 | bias 16]
+  constexpr int RW = kGemvWaves - 1;                                     // waves that hand their partial sums over
+  f32x4_t* red = reinterpret_cast<f32x4_t*>(tail);                       // [2 parities][MG][waves 1..7][64 lanes]
+  float* sc_lds = reinterpret_cast<float*>(tail + 2 * MG * RW * 64 * 16);   // [2 parities][scale 16 | bias 16]
   uint4* zero = reinterpret_cast<uint4*>(sc_lds + 64);
   pin_sgpr(W); pin_sgpr(NT); pin_sgpr(KT); pin_sgpr(M); pin_sgpr(K); pin_sgpr(G); pin_sgpr(p.x); pin_sgpr(p.ldx);
   pin_sgpr(e.scale); pin_sgpr(e.bias); pin_sgpr(e.out_f32); pin_sgpr(e.ld_out);
@@ -1188,16 +1301,32 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uin
 
   // lane -> (k offset, row) of its slot in each of the 8 DMA instructions of a sub-chunk (fixed)
   int src_off[kKsDma], src_k[kKsDma];                  // element offset inside the sub-chunk's [rows][U * TK] window (-1: no slot), its k part
+  constexpr int CPR = U * QPT;                         // 16-byte chunks of a row in a sub-chunk
 #pragma unroll
   for (int d = 0; d < kKsDma; ++d) {
-    const int sl = d * 64 + lane, q = sl / M, r = sl - q * M;
-    // slot q of the image holds the 8-element chunk xfrag_slot maps there: inside a 64-wide k-tile the
-    // chunks are interleaved (slot (h, g) <- chunk 2 g + h) to match the byte order of the 1-byte weight tiles
-    int ch = q;
-    if constexpr (WD != MI_W_BF16) ch = (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1);
-    src_off[d] = sl < slots ? r * p.ldx + ch * 8 : -1;
-    src_k[d] = ch * 8;
+    const int sl = d * 64 + lane;
+    if constexpr (MG == 1) {
+      const int q = sl / M, r = sl - q * M;
+      // slot q of the image holds the 8-element chunk xfrag_slot maps there: inside a 64-wide k-tile the
+      // chunks are interleaved (slot (h, g) <- chunk 2 g + h) to match the byte order of the 1-byte weight tiles
+      int ch = q;
+      if constexpr (WD != MI_W_BF16) ch = (q & ~7) | ((q & 3) << 1) | ((q >> 2) & 1);
+      src_off[d] = sl < slots ? r * p.ldx + ch * 8 : -1;
+      src_k[d] = ch * 8;
+    } else {
+      // 17 .. 32 rows: the [chunk][row] image above makes a DMA instruction fetch 64 pieces of 16 bytes from up to 64 different
+      // rows (64 cache lines for 1 KiB).  Row-major image instead: 16 consecutive lanes bring one row's 256 bytes (CPR = 16
+      // chunks), the chunks XOR-swizzled by the row so that the fragment reads (16 rows, one chunk position) are
+      // conflict-free; the swizzle is applied to the SOURCE address, the LDS write stays lane-linear.
+      static_assert(CPR == 16, "row-major image: 16 chunks per row and sub-chunk");
+      const int r = sl / CPR, sslot = sl % CPR;
+      const int ch = sslot ^ (r & 15);                 // natural 8-element chunk of the sub-chunk's window held by this slot
+      src_off[d] = r < M ? r * p.ldx + ch * 8 : -1;
+      src_k[d] = ch * 8;
+    }
   }
+  // fragment reads of the row-major image (MG == 2): 16-byte slot of (row, natural chunk)
+  auto rm_slot = [&](int row, int ch) { return row * CPR + (ch ^ (row & 15)); };
   auto issue_x = [&](int sel, int i) {
     const bool live = i < total;
     const int j = live ? i % nsc : 0;
@@ -1232,7 +1361,9 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uin
   float scv = 0.f, biv = 0.f;                          // scale / bias of the row-tile in flight (threads 0..15)
   __syncthreads();                                     // the zero slot
 
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[MG];
+#pragma unroll
+  for (int q = 0; q < MG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   int parity = 0;
   auto process = [&](u32x4_t (&buf)[U], int sel, int i) {
     const int it = i / nsc, j = i - it * nsc;
@@ -1247,34 +1378,55 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uin
     const int kt0 = kbeg + j * U;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool ok = col_ok && kt0 + u < kend;
+      const bool live = kt0 + u < kend;
       const u32x4_t w = buf[u];
       if constexpr (WD == MI_W_BF16) {
-        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, ok ? xf[(u * 4 + g) * M + c] : *zero);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), bb, acc, 0, 0, 0);
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+          const int at = MG == 1 ? (u * 4 + g) * M + 16 * q + c : rm_slot(16 * q + c, u * 4 + g);
+          const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, live && col_ok[q] ? xf[at] : *zero);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[q], 0, 0, 0);
+        }
       } else {
-        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, ok ? xf[((u * 2 + 0) * 4 + g) * M + c] : *zero);
-        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, ok ? xf[((u * 2 + 1) * 4 + g) * M + c] : *zero);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[0], w[1]), b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(decode8<WD>(w[2], w[3]), b1, acc, 0, 0, 0);
+        const bf16x8_t a0 = decode8<WD>(w[0], w[1]), a1 = decode8<WD>(w[2], w[3]);   // decoded once for all column groups
+#pragma unroll
+        for (int q = 0; q < MG; ++q) {
+          const bool ok = live && col_ok[q];
+          // k-tile u, MFMA h: lane group g multiplies the elements 16 g + 8 h .. of the k-tile = natural chunk 2 g + h
+          const int at0 = MG == 1 ? ((u * 2 + 0) * 4 + g) * M + 16 * q + c : rm_slot(16 * q + c, u * 8 + 2 * g);
+          const int at1 = MG == 1 ? ((u * 2 + 1) * 4 + g) * M + 16 * q + c : rm_slot(16 * q + c, u * 8 + 2 * g + 1);
+          const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, ok ? xf[at0] : *zero);
+          const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, ok ? xf[at1] : *zero);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[q], 0, 0, 0);
+        }
       }
     }
-    if (j == nsc - 1) {   // row-tile done: combine the K-slices in wave order
-      red[(parity * kGemvWaves + wave) * 64 + lane] = acc;
+    if (j == nsc - 1) {   // row-tile done: combine the K-slices in wave order (wave 0's own partial first, then waves 1..7)
+      if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < MG; ++q) red[((parity * MG + q) * RW + wave - 1) * 64 + lane] = acc[q];
+      }
       if (tid < 16) { sc_lds[parity * 32 + tid] = scv; sc_lds[parity * 32 + 16 + tid] = biv; }
       __syncthreads();
-      if (wave == 0 && col_ok && tile < NT) {
-        f32x4_t sacc = red[(parity * kGemvWaves) * 64 + lane];
+      if (wave == 0 && tile < NT) {
 #pragma unroll
-        for (int w2 = 1; w2 < kGemvWaves; ++w2) {
-          const f32x4_t t = red[(parity * kGemvWaves + w2) * 64 + lane];
-          sacc[0] += t[0]; sacc[1] += t[1]; sacc[2] += t[2]; sacc[3] += t[3];
+        for (int q = 0; q < MG; ++q) {
+          if (!col_ok[q]) continue;
+          f32x4_t sacc = acc[q];
+#pragma unroll
+          for (int w2 = 0; w2 < RW; ++w2) {
+            const f32x4_t t = red[((parity * MG + q) * RW + w2) * 64 + lane];
+            sacc[0] += t[0]; sacc[1] += t[1]; sacc[2] += t[2]; sacc[3] += t[3];
+          }
+          epilogue_lds<EPI>(e, 16 * q + c, tile * 16 + g * 4, sc_lds + parity * 32 + g * 4,
+                            e.bias ? sc_lds + parity * 32 + 16 + g * 4 : nullptr, sacc, 1.f);
         }
-        epilogue_lds<EPI>(e, c, tile * 16 + g * 4, sc_lds + parity * 32 + g * 4,
-                          e.bias ? sc_lds + parity * 32 + 16 + g * 4 : nullptr, sacc, 1.f);
       }
       parity ^= 1;
-      acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < MG; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     // the buffer is re-filled next: its fragment reads must have returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1295,17 +1447,17 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_kstream_kernel(const uin
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the work-group has gone
 }
 
-template <int WD, int EPI, int U, int ND>
+template <int WD, int EPI, int U, int ND, int MG = 1>
 static int launch_gemv_kstream_u(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
-  MI_CHECK(U * (tile_k(WD) / 8) * M <= ND * 64, "gemv_kstream: sub-chunk larger than its DMA budget");
-  auto kern = gemv_kstream_kernel<WD, EPI, U, ND>;
+  MI_CHECK(U * (tile_k(WD) / 8) * M <= ND * 64 && M <= 16 * MG, "gemv_kstream: sub-chunk larger than its DMA budget");
+  auto kern = gemv_kstream_kernel<WD, EPI, U, ND, MG>;
   MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
   int num_cu = 0;
   MI_TRY_(device_num_cu(&num_cu));
   int grid = NT;
   if (NT > num_cu) grid = ceil_div(NT, ceil_div(NT, num_cu));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), gemv_kstream_lds(), s, reinterpret_cast<const uint4*>(w.w), NT,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), gemv_kstream_lds(MG), s, reinterpret_cast<const uint4*>(w.w), NT,
                      KT, M, w.K, grid, p, e);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -1315,27 +1467,43 @@ static int launch_gemv_kstream(const LinearW& w, int M, const ProArgs& p, const 
   MI_CHECK(p.ldx % 8 == 0, "gemv: activation row stride must be a multiple of 8 elements");
   if (M <= 4) return launch_gemv_kstream_u<WD, EPI, 8, 4>(w, M, p, e, s);
   if (M <= 8) return launch_gemv_kstream_u<WD, EPI, 8, 8>(w, M, p, e, s);
-  return launch_gemv_kstream_u<WD, EPI, 4, 8>(w, M, p, e, s);
+  if (M <= 16) return launch_gemv_kstream_u<WD, EPI, 4, 8>(w, M, p, e, s);
+  // 17 .. 32 rows: two column groups over one weight stream; a sub-chunk is 2 k-tiles x 32 rows (8 KiB of activations)
+  if constexpr (WD == MI_W_BF16) return launch_gemv_kstream_u<WD, EPI, 4, 8, 2>(w, M, p, e, s);
+  else return launch_gemv_kstream_u<WD, EPI, 2, 8, 2>(w, M, p, e, s);
 }
 
-template <int WD, int PRO, int EPI>
-static int launch_gemv_bigk_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+template <int WD, int PRO, int EPI, int MG, int KS>
+static int launch_gemv_bigk_ks(const LinearW& w, int M, int TP, const ProArgs& p, const EpiArgs& e, hipStream_t s, int num_cu) {
   const int NT = w.N / 16, KT = w.K / tile_k(WD);
   const int CKT = gemv_bigk_chunk_kt(M, w.K, WD);
-  const size_t lds = (size_t)M * CKT * tile_k(WD) * 2 + gemv_bigk_fixed_lds();
+  const size_t lds = (size_t)M * CKT * tile_k(WD) * 2 + gemv_bigk_fixed_lds(MG);
   MI_CHECK(CKT >= kGemvWaves && lds <= 160 * 1024, "gemv: activation chunk does not fit in LDS");
-  auto kern = gemv_bigk_kernel<WD, PRO, EPI>;
+  auto kern = gemv_bigk_kernel<WD, PRO, EPI, MG, KS>;
   MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
-  int num_cu = 0;
-  MI_TRY_(device_num_cu(&num_cu));
-  // one row-tile per work-group at a time; more row-tiles than CUs -> every work-group walks
-  // an equal share (a grid that divides NT evenly, at most 2 per CU in flight order)
-  int grid = NT;
-  if (NT > num_cu) grid = ceil_div(NT, ceil_div(NT, num_cu));
+  // one pass (TP row-tiles) per work-group at a time; more passes than CUs -> every work-group walks an equal share
+  const int units = ceil_div(NT, TP);
+  int grid = units;
+  if (units > num_cu) grid = ceil_div(units, ceil_div(units, num_cu));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemvWaves * 64), lds, s, reinterpret_cast<const uint4*>(w.w), NT, KT, M, w.K,
-                     CKT, p, e);
+                     CKT, TP, p, e);
   MI_HIP(hipGetLastError());
   return MI_OK;
+}
+template <int WD, int PRO, int EPI>
+static int launch_gemv_bigk_t(const LinearW& w, int M, const ProArgs& p, const EpiArgs& e, hipStream_t s) {
+  int num_cu = 0;
+  MI_TRY_(device_num_cu(&num_cu));
+  // up to 16 rows: the K dimension of one row-tile over all 8 waves (the summation order the whole-image kernels' tests pin)
+  if (M <= 16) return launch_gemv_bigk_ks<WD, PRO, EPI, 1, kGemvWaves>(w, M, 1, p, e, s, num_cu);
+  // 17 .. 32 rows: as many row-tiles side by side as keep every wave streaming (gate|up of Llama-8B: 7 per work-group, one pass)
+  const GemvShape sh = gemv_pick_shape(w.N / 16, w.K / tile_k(WD), num_cu);
+  switch (sh.ks) {
+    case 1: return launch_gemv_bigk_ks<WD, PRO, EPI, 2, 1>(w, M, sh.tp, p, e, s, num_cu);
+    case 2: return launch_gemv_bigk_ks<WD, PRO, EPI, 2, 2>(w, M, sh.tp, p, e, s, num_cu);
+    case 4: return launch_gemv_bigk_ks<WD, PRO, EPI, 2, 4>(w, M, sh.tp, p, e, s, num_cu);
+    default: return launch_gemv_bigk_ks<WD, PRO, EPI, 2, 8>(w, M, sh.tp, p, e, s, num_cu);
+  }
 }
 
 // valid (prologue, epilogue) pairs: bf16 activations feed the row-parallel projections
@@ -1359,7 +1527,7 @@ static int launch_gemv_wd(const LinearW& w, int M, int pro, const ProArgs& p, in
 }
 
 int launch_gemv(const LinearW& w, int M, int pro, const ProArgs& p, int epi, const EpiArgs& e, hipStream_t s) {
-  MI_CHECK(M >= 1 && M <= 16, "gemv: M must be 1..16");
+  MI_CHECK(M >= 1 && M <= 32, "gemv: M must be 1..32");
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemv: N % 16 == 0 and K % 64 == 0 required");
   switch (w.wd) {
     case MI_W_BF16: return launch_gemv_wd<MI_W_BF16>(w, M, pro, p, epi, e, s);

@@ -157,7 +157,8 @@ int run_linear(mi_ctx* c, const Linear& L, int rows, int pro, ProArgs p, int epi
   static const bool fuse = [] { const char* v = getenv("MI355X_FUSE_SPLITK_NORM"); return !v || v[0] != '0'; }();
   // (from 384 rows on -- the 512 bucket holds 495: the norm runs one work-group per row -- with few rows the K-split sum is the wider kernel on its
   //  own; measured at 32 rows: 14.2 us fused against 5.0 + 4.6 us)
-  SlabSum* defer = (fuse && epi == EPI_RESID && rows >= 384 && !c->pend.slab) ? &c->pend : nullptr;
+  static const int fuse_min_rows = [] { const char* v = getenv("MI355X_FUSE_SPLITK_MIN_ROWS"); return v ? atoi(v) : 384; }();
+  SlabSum* defer = (fuse && epi == EPI_RESID && rows >= fuse_min_rows && !c->pend.slab) ? &c->pend : nullptr;
   auto note_deferred = [&]() {
     if (defer && c->pend.slab) { c->pend_in = e.resid_in; c->pend_out = e.out_f32; }
   };
@@ -575,7 +576,39 @@ int capture_or_launch_decode(mi_ctx* c, int B, int MB) {
 extern "C" {
 
 const char* mi_last_error(void) { return mi::g_err.c_str(); }
-int mi_version(void) { return 3; }   // 3: + in-process tensor parallelism (tp_rank = MI_TP_ALL_RANKS, tp_device_ids, tp_transport)
+int mi_version(void) { return 4; }   // 3: + in-process tensor parallelism (tp_rank = MI_TP_ALL_RANKS, tp_device_ids, tp_transport)
+
+int mi_tp_plan(const mi_model_config* cfg, int32_t rank, mi_tp_plan_t* out) {
+  MI_CHECK(cfg && out, "null argument");
+  const mi_model_config& k = *cfg;
+  const int T = k.tp_degree;
+  MI_CHECK(T >= 1 && rank >= 0 && rank < T, "mi_tp_plan: rank out of range");
+  MI_CHECK(k.num_heads > 0 && k.num_kv_heads > 0 && k.num_heads % k.num_kv_heads == 0, "num_heads must be a multiple of num_kv_heads");
+  MI_CHECK(k.num_kv_heads >= T ? k.num_kv_heads % T == 0 : T % k.num_kv_heads == 0,
+           "num_kv_heads must be a multiple or a divisor of tp_degree");
+  MI_CHECK(k.intermediate_size % T == 0 && k.vocab_size % T == 0, "intermediate_size and vocab_size must divide by tp_degree");
+  const int G = k.num_heads / k.num_kv_heads;
+  mi_tp_plan_t p{};
+  if (k.num_kv_heads >= T) {       // whole kv groups per rank
+    p.kv_heads_local = k.num_kv_heads / T;
+    p.q_heads_local = p.q_heads_real = p.kv_heads_local * G;
+    p.kv_head0 = rank * p.kv_heads_local;
+    p.q_head0 = p.kv_head0 * G;
+  } else {                         // every kv head on R ranks, its G q heads dealt ceil(G / R) at a time, the tail zero-weight padding
+    const int R = T / k.num_kv_heads, Gl = (G + R - 1) / R, sub = rank % R;
+    p.kv_heads_local = 1;
+    p.q_heads_local = Gl;
+    p.kv_head0 = rank / R;
+    p.q_head0 = std::min(p.kv_head0 * G + sub * Gl, (p.kv_head0 + 1) * G);
+    p.q_heads_real = std::max(0, std::min(Gl, G - sub * Gl));
+  }
+  p.inter_local = k.intermediate_size / T;
+  p.inter0 = rank * p.inter_local;
+  p.vocab_local = k.vocab_size / T;
+  p.vocab0 = rank * p.vocab_local;
+  *out = p;
+  return MI_OK;
+}
 
 int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   MI_CHECK(cfg && out, "null argument");
@@ -628,28 +661,18 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   // they add nothing to the row-parallel sum) -- Qwen2.5-7B at TP 8: 28 q / 4 kv heads -> 4 + 3(+1 pad) per kv
   // head.  The reference runs such models because it skips vLLM's divisibility check (platform.py:58-64) and
   // its model library pads heads the same way.
-  MI_CHECK(k.num_kv_heads >= T ? k.num_kv_heads % T == 0 : T % k.num_kv_heads == 0,
-           "num_kv_heads must be a multiple or a divisor of tp_degree");
-  const int G = k.num_heads / k.num_kv_heads;
-  const int tr = c->cfg.tp_rank;
-  if (k.num_kv_heads >= T) {
-    c->nkv_l = k.num_kv_heads / T;
-    c->nh_l = c->nh_real = c->nkv_l * G;
-    c->kvh0 = tr * c->nkv_l;
-    c->qh0 = c->kvh0 * G;
-  } else {
-    const int R = T / k.num_kv_heads, Gl = (G + R - 1) / R, sub = tr % R;
-    c->nkv_l = 1;
-    c->nh_l = Gl;
-    c->kvh0 = tr / R;
-    c->qh0 = std::min(c->kvh0 * G + sub * Gl, (c->kvh0 + 1) * G);
-    c->nh_real = std::max(0, std::min(Gl, G - sub * Gl));
-  }
+  mi_tp_plan_t plan;
+  MI_TRY(mi_tp_plan(&c->cfg, c->cfg.tp_rank, &plan));   // (host arithmetic only; exported so that the plan can be tested without a GPU)
+  c->nkv_l = plan.kv_heads_local;
+  c->nh_l = plan.q_heads_local;
+  c->nh_real = plan.q_heads_real;
+  c->kvh0 = plan.kv_head0;
+  c->qh0 = plan.q_head0;
   MI_CHECK(c->nh_l % c->nkv_l == 0 && c->nh_l / c->nkv_l <= 8, "q heads per kv head (per rank) must be 1..8");
   c->q_dim = c->nh_l * c->hd;
   c->kv_dim = c->nkv_l * c->hd;
-  c->I_l = k.intermediate_size / T;
-  c->V_l = k.vocab_size / T;
+  c->I_l = plan.inter_local;
+  c->V_l = plan.vocab_local;
   int maxb = k.max_model_len;
   for (int i = 0; i < k.num_ctx_buckets && i < 8; ++i) maxb = std::max(maxb, k.ctx_buckets[i]);
   c->max_rows = std::max(maxb, k.max_num_seqs);
@@ -1150,7 +1173,7 @@ static int sample_on_device(mi_ctx* c, int nrows, int row0, const float* samplin
     mi_ctx* c0 = c->grp->ranks[0];
     const size_t per_rank = (size_t)k.max_num_seqs * c->V_l;
     float* dst = c0->logits_all + (size_t)k.tp_rank * per_rank;
-    if (c->grp->lockstep) MI_HIP(hipMemcpyAsync(dst, c->logits, per_rank * 4, hipMemcpyDeviceToDevice, s));
+    if (c->grp->same_device) MI_HIP(hipMemcpyAsync(dst, c->logits, per_rank * 4, hipMemcpyDeviceToDevice, s));
     else MI_HIP(hipMemcpyPeerAsync(dst, c0->cfg.device_id, c->logits, k.device_id, per_rank * 4, s));
     MI_HIP(hipStreamSynchronize(s));
     MI_TRY(group_check_errors(c));
@@ -1509,7 +1532,10 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   }
   // ---- tensor-parallel target: the same phases, every shard on its own thread ----
   hipEvent_t ids_ready = nullptr;
-  if (!g->lockstep) MI_HIP(hipEventCreateWithFlags(&ids_ready, hipEventDisableTiming));
+  if (!g->lockstep) {
+    MI_HIP(hipSetDevice(kt.device_id));   // the event is recorded on shard 0's stream: it belongs to shard 0's device
+    MI_HIP(hipEventCreateWithFlags(&ids_ready, hipEventDisableTiming));
+  }
   int rc = group_run(g, [&](mi_ctx* rcx, int r) -> int {
     MI_TRY(stage_target(rcx));
     if (r != 0) return MI_OK;
@@ -1626,6 +1652,12 @@ int mi_profile_read(mi_ctx* c, int32_t* launches, float* ms, double* gemv_weight
   for (int i = 0; i < MI_K_NUM; ++i) { launches[i] = c->prof.launches[i]; ms[i] = c->prof.ms[i]; }
   if (gemv_weight_bytes) *gemv_weight_bytes = c->prof.gemv_bytes;
   return MI_OK;
+}
+
+int mi_tp_info(mi_ctx* c, mi_tp_info_t* out) {
+  MI_CHECK(c && out, "null argument");
+  MI_CHECK(c->owned_group != nullptr, "mi_tp_info: not an in-process tensor-parallel context (tp_rank = MI_TP_ALL_RANKS, tp_degree > 1)");
+  return group_info(c->owned_group, out);
 }
 
 int mi_tp_unique_id(void* out128) {

@@ -64,7 +64,11 @@ class HostBarrier {
 
 struct mi_group {
   int T = 0;
-  bool lockstep = false;                 // every shard on ONE device: shared stream, host barriers between exchange phases
+  bool same_device = false;              // every shard on ONE device (single-GPU loopback)
+  bool lockstep = false;                 // ... with a shared stream and host barriers between the exchange kernels (the default loopback form)
+  int selftest = 0;                      // 1 passed, -1 peer-memory exchange failed (RCCL took over), -2 both failed, 0 not run
+  int device_ids[16] = {0};
+  int peer_access[16] = {0};             // bit p of word r: rank r's device maps rank p's memory
   std::vector<mi_ctx*> ranks;
   hipStream_t shared_stream = nullptr;   // lockstep only
   mi::HostBarrier* bar = nullptr;
@@ -99,5 +103,6 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count);
 int group_selftest(mi_group* g);
 // device-side error word of rank c (nonzero: an exchange kernel gave up waiting)
 int group_check_errors(mi_ctx* c);
+int group_info(mi_group* g, mi_tp_info_t* out);
 
 }  // namespace mi

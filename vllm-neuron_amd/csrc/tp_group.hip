@@ -49,9 +49,13 @@ void HostBarrier::reset() {
 // exchange kernels
 // =====================================================================================
 constexpr int kArThreads = 256;
-constexpr unsigned kArSpinMax = 1u << 20;   // bounded wait: ~1-2 s, then the error word is set and the kernel goes on
+// A flag wait is bounded in TIME (s_memrealtime: the 100 MHz constant clock), not in iterations: a peer's rank thread
+// parked by the host scheduler for tens of milliseconds, or its first graph instantiation, must not trip it, a dead peer must.
+// On expiry the kernel sets the error word AND poisons what it would have written (NaN): a partial sum never passes as data;
+// the host reports MI_ECOMM after the step (group_check_errors).  MI355X_TP_TIMEOUT_MS, default 5000.
+constexpr unsigned long long kArTicksPerMs = 100000ull;
 
-enum { AR_EPOCH_PUB = 0, AR_EPOCH_RS = 1, AR_TICKET_PUB = 4, AR_TICKET_RS = 5, AR_ERROR = 8, AR_WORDS = 16 };
+enum { AR_EPOCH_PUB = 0, AR_EPOCH_RS = 1, AR_TICKET_PUB = 4, AR_TICKET_RS = 5, AR_ERROR = 8, AR_TOUCH = 12, AR_WORDS = 16 };
 
 struct ArGeom {
   int T, r, G;          // ranks, this rank, work-groups
@@ -61,30 +65,48 @@ struct ArGeom {
   unsigned cps;         // chunks per rank slice (two-shot)
   size_t cap;           // elements per exchange slot
   size_t ycap;          // elements per reduced-slice slot
+  unsigned long long timeout;   // flag-wait bound in 100 MHz ticks
 };
 
 __device__ __forceinline__ bool flag_reached(const uint32_t* p, uint32_t e) {
   const uint32_t v = __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
   return (int32_t)(v - e) >= 0;
 }
-// wait until work-groups 0 .. nG-1 of every peer have signalled epoch e in this rank's flag block
-__device__ __forceinline__ void wait_flags(const uint32_t* flags, int T, int self, int nG, uint32_t e, uint32_t* err) {
+// one flag, bounded in time; false = gave up (error word set)
+__device__ __forceinline__ bool wait_flag(const uint32_t* p, uint32_t e, unsigned long long timeout, uint32_t* err) {
+  if (flag_reached(p, e)) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    __builtin_amdgcn_s_sleep(8);
+    if (flag_reached(p, e)) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+}
+// wait until work-groups 0 .. nG-1 of every peer have signalled epoch e in this rank's flag block; false (for the whole
+// work-group) when any wait gave up
+__device__ __forceinline__ bool wait_flags(const uint32_t* flags, int T, int self, int nG, uint32_t e, unsigned long long timeout,
+                                           uint32_t* err) {
+  __shared__ int s_gave_up;
+  if (threadIdx.x == 0) s_gave_up = 0;
+  __syncthreads();
   for (int i = threadIdx.x; i < T * nG; i += blockDim.x) {
     const int p = i / nG, w = i - p * nG;
     if (p == self) continue;   // a rank does not signal itself
-    unsigned it = 0;
-    while (!flag_reached(flags + p * kArMaxBlocks + w, e)) {
-      if (++it >= kArSpinMax) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
+    if (!wait_flag(flags + p * kArMaxBlocks + w, e, timeout, err)) s_gave_up = 1;
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope, every wave: drop stale lines of the peers' buffers
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  return s_gave_up == 0;
+}
+__device__ __forceinline__ void store8_nan(float* o) {
+  const float n = __builtin_nanf("");
+  *reinterpret_cast<float4*>(o) = make_float4(n, n, n, n);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(n, n, n, n);
 }
 // the last work-group of a kernel advances its epoch counter (every work-group read it at entry)
 __device__ __forceinline__ void advance_epoch(uint32_t* ctr, int epoch_idx, int ticket_idx, uint32_t e, int G) {
@@ -174,25 +196,21 @@ __global__ __launch_bounds__(kArThreads) void ar_reduce_kernel(float* __restrict
   const int w = blockIdx.x;
   const uint32_t e = read_epoch(ctr, AR_EPOCH_PUB);   // the publish kernel in front of this one has advanced it
   // the peers' flags for work-group w: word p * kArMaxBlocks + w of this rank's block
+  __shared__ int s_gave_up;
+  if (threadIdx.x == 0) s_gave_up = 0;
+  __syncthreads();
   {
     const int t = threadIdx.x;
-    if (t < ge.T && t != ge.r) {
-      unsigned it = 0;
-      while (!flag_reached(P.flag1[ge.r] + t * kArMaxBlocks + w, e)) {
-        if (++it >= kArSpinMax) {
-          __hip_atomic_store(ctr + AR_ERROR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
+    if (t < ge.T && t != ge.r && !wait_flag(P.flag1[ge.r] + t * kArMaxBlocks + w, e, ge.timeout, ctr + AR_ERROR)) s_gave_up = 1;
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope, every wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  const bool ok = s_gave_up == 0;
   const unsigned c0 = (unsigned)w * ge.cpw, c1 = min(c0 + ge.cpw, ge.chunks);
   for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+    if (!ok) { store8_nan(out + (size_t)ch * 8); continue; }   // a peer never published: no partial sum leaves this kernel
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < ge.T; ++p) wire_add8<F32>(acc, wire_slot<F32>(P.xbuf[p], e, ge.cap), ch);
     store8(out + (size_t)ch * 8, acc);
@@ -206,12 +224,13 @@ __global__ __launch_bounds__(kArThreads) void ar_reduce_scatter_kernel(float* __
   const uint32_t e = read_epoch(ctr, AR_EPOCH_PUB);
   const uint32_t e2 = read_epoch(ctr, AR_EPOCH_RS) + 1;
   // any publishing work-group of a peer may have written part of this range: wait for all of them
-  wait_flags(P.flag1[ge.r], ge.T, ge.r, ge.pubG, e, ctr + AR_ERROR);
+  const bool ok = wait_flags(P.flag1[ge.r], ge.T, ge.r, ge.pubG, e, ge.timeout, ctr + AR_ERROR);
   uint16_t* yslot = P.ybuf[ge.r] + (size_t)(e2 & 1) * ge.ycap;
   const unsigned s0 = min((unsigned)ge.r * ge.cps, ge.chunks), s1 = min(s0 + ge.cps, ge.chunks);
   const unsigned c0 = min(s0 + (unsigned)w * ge.cpw, s1), c1 = min(c0 + ge.cpw, s1);
+  const float poison = ok ? 0.f : __builtin_nanf("");   // gave up: the slice this rank publishes (and keeps) is NaN, the protocol goes on
   for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[8] = {poison, poison, poison, poison, poison, poison, poison, poison};
     for (int p = 0; p < ge.T; ++p) wire_add8<false>(acc, wire_slot<false>(P.xbuf[p], e, ge.cap), ch);
     const u32x4_t pk = pack8(make_float4(acc[0], acc[1], acc[2], acc[3]), make_float4(acc[4], acc[5], acc[6], acc[7]));
     *reinterpret_cast<u32x4_t*>(yslot + (size_t)(ch - s0) * 8) = pk;
@@ -232,18 +251,40 @@ __global__ __launch_bounds__(kArThreads) void ar_gather_kernel(float* __restrict
                                                                uint32_t* __restrict__ ctr) {
   const int w = blockIdx.x;
   const uint32_t e2 = read_epoch(ctr, AR_EPOCH_RS);
-  wait_flags(P.flag2[ge.r], ge.T, ge.r, ge.G, e2, ctr + AR_ERROR);
+  const bool ok = wait_flags(P.flag2[ge.r], ge.T, ge.r, ge.G, e2, ge.timeout, ctr + AR_ERROR);
   for (int p = 0; p < ge.T; ++p) {
     if (p == ge.r) continue;
     const uint16_t* yslot = P.ybuf[p] + (size_t)(e2 & 1) * ge.ycap;
     const unsigned s0 = min((unsigned)p * ge.cps, ge.chunks), s1 = min(s0 + ge.cps, ge.chunks);
     const unsigned c0 = min(s0 + (unsigned)w * ge.cpw, s1), c1 = min(c0 + ge.cpw, s1);
     for (unsigned ch = c0 + threadIdx.x; ch < c1; ch += kArThreads) {
+      if (!ok) { store8_nan(out + (size_t)ch * 8); continue; }
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       add8(v, *reinterpret_cast<const u32x4_t*>(yslot + (size_t)(ch - s0) * 8));
       store8(out + (size_t)ch * 8, v);
     }
   }
+}
+
+// One word of every rank's slots and flag blocks read from THIS rank (and thereby mapped / first-touched from it) before
+// the first exchange: see group_alloc_exchange.
+__global__ void ar_touch_kernel(ArPeers P, int T, size_t cap, size_t ycap, uint32_t* __restrict__ ctr) {
+  const int p = threadIdx.x;
+  if (p >= T) return;
+  uint32_t acc = 0;
+  acc += __hip_atomic_load(reinterpret_cast<const uint32_t*>(P.xbuf[p]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  acc += __hip_atomic_load(reinterpret_cast<const uint32_t*>(P.xbuf[p]) + cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // second slot (fp32-sized)
+  acc += __hip_atomic_load(reinterpret_cast<const uint32_t*>(P.ybuf[p]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  acc += __hip_atomic_load(reinterpret_cast<const uint32_t*>(P.ybuf[p] + ycap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  acc += __hip_atomic_load(P.flag1[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  acc += __hip_atomic_load(P.flag2[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  atomicAdd(ctr + AR_TOUCH, acc);     // everything was zero-filled by its owner: the word stays 0
+}
+
+static unsigned long long ar_timeout_ticks(int* ms_out = nullptr) {
+  static const int ms = [] { const char* v = getenv("MI355X_TP_TIMEOUT_MS"); const int m = v ? atoi(v) : 5000; return m > 0 ? m : 5000; }();
+  if (ms_out) *ms_out = ms;
+  return (unsigned long long)ms * kArTicksPerMs;
 }
 
 // =====================================================================================
@@ -317,8 +358,15 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
   MI_CHECK(same || distinct, "tp_device_ids must be all distinct (one GPU per rank) or all equal (single-GPU loopback)");
   mi_group* g = new mi_group();
   g->T = T;
-  g->lockstep = same;
+  g->same_device = same;
+  // Single-GPU loopback, two forms.  Lockstep (default): one stream for all shards, host barriers between the exchange
+  // kernels -- a reducer never waits on the device.  Concurrent (MI355X_TP_LOOPBACK_CONCURRENT=1): one stream per shard, no
+  // host barrier, hipGraphs as configured -- publish / reduce kernels of different shards run side by side and wait on the
+  // device flags exactly as they will across GPUs (the waits are bounded, so a scheduling problem is a failed call, not a hang).
+  const bool concurrent = same && getenv("MI355X_TP_LOOPBACK_CONCURRENT") && getenv("MI355X_TP_LOOPBACK_CONCURRENT")[0] == '1';
+  g->lockstep = same && !concurrent;
   g->use_rccl = (!same && cfg.tp_transport == MI_TP_TRANSPORT_RCCL) ? 1 : 0;
+  for (int r = 0; r < T; ++r) { g->device_ids[r] = cfg.tp_device_ids[r]; g->peer_access[r] = same ? (1 << T) - 1 : (1 << r); }
   g->bar = new HostBarrier(T);
   g->ranks.assign(T, nullptr);
   g->rc.assign(T, MI_OK);
@@ -341,6 +389,7 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
           hipError_t pe = hipDeviceEnablePeerAccess(cfg.tp_device_ids[p], 0);
           if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) MI_HIP(pe);
           (void)hipGetLastError();
+          g->peer_access[r] |= 1 << p;
         }
       }
     }
@@ -387,15 +436,21 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
 void group_destroy(mi_group* g) {
   if (!g) return;
   if (!g->threads.empty()) {
-    group_run(g, [&](mi_ctx* c, int r) -> int {
-      if (c) {
-        if (g->counters[r]) hipFree(g->counters[r]);
-        void* p[] = {g->peers.xbuf[r], g->peers.ybuf[r], g->peers.flag1[r], g->peers.flag2[r]};
-        for (void* q : p) if (q) hipFree(q);
-        mi_ctx_destroy(c);
-      }
+    // every shard drains its stream first; the lockstep form shares rank 0's stream, so rank 0 (its owner) goes last
+    group_run(g, [&](mi_ctx* c, int) -> int {
+      if (c) hipStreamSynchronize(c->stream);
       return MI_OK;
     });
+    for (int phase = 0; phase < 2; ++phase)
+      group_run(g, [&](mi_ctx* c, int r) -> int {
+        if (c && (phase == 0) == (r != 0)) {
+          if (g->counters[r]) hipFree(g->counters[r]);
+          void* p[] = {g->peers.xbuf[r], g->peers.ybuf[r], g->peers.flag1[r], g->peers.flag2[r]};
+          for (void* q : p) if (q) hipFree(q);
+          mi_ctx_destroy(c);
+        }
+        return MI_OK;
+      });
     {
       std::lock_guard<std::mutex> lk(g->mu);
       g->stop = true;
@@ -429,12 +484,20 @@ int group_alloc_exchange(mi_ctx* c) {
     const size_t cap = (size_t)c->max_rows * c->H;
     const size_t ycap = ((cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
     void *xb = nullptr, *yb = nullptr, *f1 = nullptr, *f2 = nullptr, *ct = nullptr;
-    if (alloc_exchange_mem(&xb, 2 * cap * 4, false) != MI_OK) return MI_EHIP;   // two slots, fp32-sized (token generation sends fp32)
-    if (alloc_exchange_mem(&yb, 2 * ycap * 2, false) != MI_OK) return MI_EHIP;
+    const bool slots_uncached = getenv("MI355X_TP_SLOTS_UNCACHED") != nullptr;   // (the round-2 layout, for the one-off check of the clear above)
+    if (alloc_exchange_mem(&xb, 2 * cap * 4, slots_uncached) != MI_OK) return MI_EHIP;   // two slots, fp32-sized (token generation sends fp32)
+    if (alloc_exchange_mem(&yb, 2 * ycap * 2, slots_uncached) != MI_OK) return MI_EHIP;
     const size_t fbytes = (size_t)T * kArMaxBlocks * 4;
     if (alloc_exchange_mem(&f1, fbytes, true) != MI_OK) return MI_EHIP;
     if (alloc_exchange_mem(&f2, fbytes, true) != MI_OK) return MI_EHIP;
     MI_HIP(hipMalloc(&ct, AR_WORDS * 4));
+    // EVERY exchange allocation is written by its owner before its address is published: round 2 lost the peers'
+    // contribution in the FIRST exchange after allocation (4 KiB-aligned ranges, data in place when the host looked later)
+    // with never-written slots in uncached memory, and never with the flag blocks, which differed only in being cleared here.
+    // What fits that evidence is the allocator's own (lazy, page-granular) initialisation of a fresh allocation landing
+    // after the first peer writes; a completed owner-side clear closes that window whatever the memory type.
+    MI_HIP(hipMemsetAsync(xb, 0, 2 * cap * 4, c->stream));
+    MI_HIP(hipMemsetAsync(yb, 0, 2 * ycap * 2, c->stream));
     MI_HIP(hipMemsetAsync(f1, 0, fbytes, c->stream));
     MI_HIP(hipMemsetAsync(f2, 0, fbytes, c->stream));
     MI_HIP(hipMemsetAsync(ct, 0, AR_WORDS * 4, c->stream));
@@ -449,6 +512,14 @@ int group_alloc_exchange(mi_ctx* c) {
   }
   // every rank's pointers are in the table before anyone launches an exchange
   MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
+  if (!g->use_rccl) {
+    // ... and every rank has read one word of every peer's slots and flags (mapped and touched from here) before the first exchange
+    const size_t ycap = ((g->cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
+    hipLaunchKernelGGL(ar_touch_kernel, dim3(1), dim3(64), 0, c->stream, g->peers, T, g->cap, ycap, g->counters[r]);
+    MI_HIP(hipGetLastError());
+    MI_HIP(hipStreamSynchronize(c->stream));
+    MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
+  }
   return MI_OK;
 }
 
@@ -468,6 +539,7 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
   ArGeom ge{};
   ge.T = T; ge.r = r; ge.chunks = (unsigned)(count / 8); ge.cap = g->cap;
   ge.ycap = ((g->cap / 8 + T - 1) / T + kArMaxBlocks) * 8;
+  ge.timeout = ar_timeout_ticks();
   const bool two_shot = count * 2 >= kArTwoShotBytes && T > 2;
   uint32_t* ctr = g->counters[r];
   // publish: one chunk per thread where the message allows it
@@ -560,7 +632,8 @@ int group_selftest(mi_group* g) {
     return rc;
   };
   int rc = run();
-  if (rc == MI_OK || g->use_rccl || g->lockstep) return rc;
+  g->selftest = rc == MI_OK ? 1 : -1;
+  if (rc == MI_OK || g->use_rccl || g->same_device) return rc;
   // the peer-memory exchange did not deliver on this machine: RCCL instead
   fprintf(stderr, "[mi355x] tensor-parallel exchange over peer memory failed its self-test (%s); falling back to RCCL\n",
           mi_last_error());
@@ -578,7 +651,21 @@ int group_selftest(mi_group* g) {
   }
   g->use_rccl = 1;
   g->bar->reset();
-  return run();
+  rc = run();
+  if (rc != MI_OK) g->selftest = -2;   // neither transport delivered
+  return rc;
+}
+
+int group_info(mi_group* g, mi_tp_info_t* o) {
+  memset(o, 0, sizeof(*o));
+  o->tp_degree = g->T;
+  o->transport = g->use_rccl ? MI_TP_TRANSPORT_RCCL : MI_TP_TRANSPORT_P2P;
+  o->selftest = g->selftest;
+  o->graphs = g->ranks.empty() || !g->ranks[0] ? 0 : g->ranks[0]->cfg.use_graphs;
+  o->mode = !g->same_device ? 0 : (g->lockstep ? 1 : 2);
+  ar_timeout_ticks(&o->timeout_ms);
+  for (int r = 0; r < g->T && r < 16; ++r) { o->device_ids[r] = g->device_ids[r]; o->peer_access[r] = g->peer_access[r]; }
+  return MI_OK;
 }
 
 int group_check_errors(mi_ctx* c) {
