@@ -232,62 +232,127 @@ def test_product_code_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
 
 
-# ---- tensor-parallel plan over gloo (world_size 2) ------------------------------------------------
-def _tp_rank_main(rank, world, port, q):
+# ---- tensor-parallel plan over gloo (world_size 2), slices taken from the LIBRARY's plan --------------
+def _plan_of(cfg_kw, rank):
+    """mi_tp_plan of libmi355x_vllm.so: host arithmetic only (no GPU, no context) -- the function mi_ctx_create itself runs."""
+    import ctypes
+    from vllm_neuron_amd import _native as N
+    L = N.load_library()
+    cfg = N.MiModelConfig()
+    for k, v in cfg_kw.items():
+        setattr(cfg, k, v)
+    plan = N.MiTpPlan()
+    N.check(L.mi_tp_plan(ctypes.byref(cfg), rank, ctypes.byref(plan)))
+    return plan
+
+
+def _attention(q, k, v, nh, nkv, hd):
+    """Causal attention of M tokens (one sequence), q [M, nh*hd], k / v [M, nkv*hd]; q head j reads kv head j // (nh // nkv)."""
+    M = q.shape[0]
+    qh, kh, vh = q.reshape(M, nh, hd), k.reshape(M, nkv, hd), v.reshape(M, nkv, hd)
+    g = nh // nkv
+    s = torch.einsum("mhd,nhd->hmn", qh, kh.repeat_interleave(g, 1)) / hd ** 0.5
+    s = s.masked_fill(torch.triu(torch.ones(M, M, dtype=torch.bool), 1)[None], float("-inf"))
+    return torch.einsum("hmn,nhd->mhd", torch.softmax(s, -1), vh.repeat_interleave(g, 1)).reshape(M, nh * hd)
+
+
+def _block_unsharded(x, w, nh, nkv, hd):
+    a = _attention(x @ w["q"].t() + w["qb"], x @ w["k"].t(), x @ w["v"].t(), nh, nkv, hd)
+    h = x + a @ w["o"].t()
+    h = h + (torch.nn.functional.silu(h @ w["g"].t()) * (h @ w["u"].t())) @ w["d"].t()
+    return h @ w["lm"].t()
+
+
+def _rank_partials(x, w, plan, hd):
+    """What tensor-parallel rank `plan` contributes: its q heads (zero-weight PADDING heads where the plan holds more
+    heads than are real: q rows, q bias and o_proj columns zero), its kv heads, the matching o_proj columns."""
+    q0, qr, ql = plan.q_head0, plan.q_heads_real, plan.q_heads_local
+    k0, kl = plan.kv_head0, plan.kv_heads_local
+    H = x.shape[1]
+    wq, bq, wo = torch.zeros(ql * hd, H), torch.zeros(ql * hd), torch.zeros(H, ql * hd)
+    wq[:qr * hd], bq[:qr * hd], wo[:, :qr * hd] = w["q"][q0 * hd:(q0 + qr) * hd], w["qb"][q0 * hd:(q0 + qr) * hd], w["o"][:, q0 * hd:(q0 + qr) * hd]
+    wk, wv = w["k"][k0 * hd:(k0 + kl) * hd], w["v"][k0 * hd:(k0 + kl) * hd]
+    a = _attention(x @ wq.t() + bq, x @ wk.t(), x @ wv.t(), ql, kl, hd)
+    return a @ wo.t()
+
+
+def _tp_rank_main(rank, world, port, case):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    name, T, nh, nkv, hd, H, I, V = case
     torch.manual_seed(0)
-    H, nh, nkv, hd, I, V, M = 64, 4, 2, 16, 96, 128, 3
+    M = 5
     x = torch.randn(M, H)
-    wq, wk = torch.randn(nh * hd, H), torch.randn(nkv * hd, H)
-    wo, wg, wu, wd = torch.randn(H, nh * hd), torch.randn(I, H), torch.randn(I, H), torch.randn(H, I)
-    wlm = torch.randn(V, H)
-    # the plan libmi355x_vllm's route_matrix applies per rank: q/kv heads and gate/up/lm_head
-    # rows are column-parallel slices, o_proj / down_proj take the matching K slices
-    nh_l, nkv_l, I_l, V_l = nh // world, nkv // world, I // world, V // world
-    q = (x @ wq[rank * nh_l * hd:(rank + 1) * nh_l * hd].t())
-    k = (x @ wk[rank * nkv_l * hd:(rank + 1) * nkv_l * hd].t())
-    attn_like = q * k.repeat(1, nh_l // nkv_l)                      # stand-in for the per-head attention
-    o_part = attn_like @ wo[:, rank * nh_l * hd:(rank + 1) * nh_l * hd].t()
-    dist.all_reduce(o_part)                                         # C1 of SURVEY.md §2.2
+    w = dict(q=torch.randn(nh * hd, H) / 8, qb=torch.randn(nh * hd) / 8, k=torch.randn(nkv * hd, H) / 8, v=torch.randn(nkv * hd, H) / 8,
+             o=torch.randn(H, nh * hd) / 8, g=torch.randn(I, H) / 8, u=torch.randn(I, H) / 8, d=torch.randn(H, I) / 8,
+             lm=torch.randn(V, H) / 8)
+    cfg_kw = dict(num_layers=1, hidden_size=H, num_heads=nh, num_kv_heads=nkv, head_dim=hd, intermediate_size=I, vocab_size=V, tp_degree=T)
+    mine = [r for r in range(T) if r % world == rank]                 # this process plays TP ranks rank, rank + world, ...
+    plans = {r: _plan_of(cfg_kw, r) for r in mine}
+    # C1 (SURVEY 2.2): all-reduce of the row-parallel o_proj partials
+    o_part = sum(_rank_partials(x, w, plans[r], hd) for r in mine)
+    dist.all_reduce(o_part)
     h = x + o_part
-    act = torch.nn.functional.silu(h @ wg[rank * I_l:(rank + 1) * I_l].t()) * (h @ wu[rank * I_l:(rank + 1) * I_l].t())
-    d_part = act @ wd[:, rank * I_l:(rank + 1) * I_l].t()
+    d_part = torch.zeros(M, H)
+    for r in mine:
+        p = plans[r]
+        sl = slice(p.inter0, p.inter0 + p.inter_local)
+        d_part += (torch.nn.functional.silu(h @ w["g"][sl].t()) * (h @ w["u"][sl].t())) @ w["d"][:, sl].t()
     dist.all_reduce(d_part)
     h = h + d_part
-    logits_l = h @ wlm[rank * V_l:(rank + 1) * V_l].t()
-    parts = [torch.empty_like(logits_l) for _ in range(world)]
-    dist.all_gather(parts, logits_l)                                # C2
-    logits = torch.cat(parts, dim=1)
-    # unsharded reference
-    qf, kf = x @ wq.t(), x @ wk.t()
-    a = qf * kf.reshape(M, nkv, hd).repeat_interleave(nh // nkv, 1).reshape(M, nh * hd)
-    h0 = x + a @ wo.t()
-    h0 = h0 + (torch.nn.functional.silu(h0 @ wg.t()) * (h0 @ wu.t())) @ wd.t()
-    ok = torch.allclose(logits, h0 @ wlm.t(), rtol=1e-4, atol=1e-3)
-    # the unique-id hand-off the worker performs (128 opaque bytes from rank 0)
-    obj = [bytes(range(128)) if rank == 0 else None]
-    dist.broadcast_object_list(obj, src=0)
-    if rank == 0:
-        q_ok = ok and obj[0] == bytes(range(128))
-    else:
-        q_ok = ok and obj[0] == bytes(range(128))
-    gathered = [None] * world
-    dist.all_gather_object(gathered, bool(q_ok))
+    # C2: vocabulary-parallel logits, every rank's slice into its own columns
+    logits = torch.zeros(M, V)
+    for r in mine:
+        p = plans[r]
+        logits[:, p.vocab0:p.vocab0 + p.vocab_local] = h @ w["lm"][p.vocab0:p.vocab0 + p.vocab_local].t()
+    dist.all_reduce(logits)                                            # (disjoint columns: a sum is a gather)
+    ok = torch.allclose(logits, _block_unsharded(x, w, nh, nkv, hd), rtol=1e-4, atol=1e-4)
+    # every q head is computed exactly once over the ranks, every kv head by all the ranks that need it
+    heads = []
+    for r in mine:
+        heads += list(range(plans[r].q_head0, plans[r].q_head0 + plans[r].q_heads_real))
+    all_heads = [None] * world
+    dist.all_gather_object(all_heads, heads)
+    covered = sorted(h for hs in all_heads for h in hs) == list(range(nh))
+    res = [None] * world
+    dist.all_gather_object(res, bool(ok and covered))
     dist.destroy_process_group()
     if rank == 0:
-        assert all(gathered), gathered
+        assert all(res), (name, res)
 
 
-def test_tp_plan_two_ranks_gloo():
+@pytest.mark.parametrize("case", [
+    ("llama-like, kv heads divide", 2, 8, 2, 16, 64, 96, 128),
+    ("kv head replicated on 2 ranks each", 4, 8, 2, 16, 64, 96, 128),
+    ("Qwen2.5-7B head counts at TP 8: 28 q / 4 kv -> 4 + 3 (+1 zero-weight padding head) per kv head", 8, 28, 4, 8, 64, 128, 256),
+])
+def test_tp_plan_two_ranks_gloo(case):
+    """SURVEY 8e on PRODUCT code: every rank's slices come from the library's own sharding plan (mi_tp_plan = what
+    mi_ctx_create / route_matrix apply), the partial sums cross a real all-reduce (gloo, world_size 2: each process plays
+    half of the TP ranks), and the result equals the unsharded block -- including head counts that do not divide
+    (reference: tp_degree = tensor_parallel_size, loader.py:752-753; no divisibility check, platform.py:58-64)."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_tp_rank_main, args=(2, port, None), nprocs=2, join=True)
+    mp.spawn(_tp_rank_main, args=(2, port, case), nprocs=2, join=True)
+
+
+def test_tp_plan_values_and_errors():
+    p = [_plan_of(dict(num_heads=28, num_kv_heads=4, head_dim=128, intermediate_size=18944, vocab_size=152064, tp_degree=8), r) for r in range(8)]
+    assert [(q.q_head0, q.q_heads_real, q.q_heads_local, q.kv_head0) for q in p] == [
+        (0, 4, 4, 0), (4, 3, 4, 0), (7, 4, 4, 1), (11, 3, 4, 1), (14, 4, 4, 2), (18, 3, 4, 2), (21, 4, 4, 3), (25, 3, 4, 3)]
+    assert all(q.kv_heads_local == 1 and q.inter_local == 2368 and q.vocab_local == 19008 for q in p)
+    assert [q.inter0 for q in p] == [2368 * r for r in range(8)]
+    q = _plan_of(dict(num_heads=64, num_kv_heads=8, head_dim=128, intermediate_size=28672, vocab_size=128256, tp_degree=8), 5)   # Llama-3.3-70B
+    assert (q.q_head0, q.q_heads_real, q.q_heads_local, q.kv_head0, q.kv_heads_local, q.vocab0) == (40, 8, 8, 5, 1, 5 * 16032)
+    with pytest.raises(ValueError):
+        _plan_of(dict(num_heads=32, num_kv_heads=8, head_dim=128, intermediate_size=14336, vocab_size=128256, tp_degree=3), 0)
+    with pytest.raises(ValueError):
+        _plan_of(dict(num_heads=32, num_kv_heads=8, head_dim=128, intermediate_size=14336, vocab_size=128256, tp_degree=2), 2)
 
 
 # ---- on-device sampling rule (oracle/sampling.py) -------------------------------------------------

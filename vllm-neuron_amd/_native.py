@@ -251,6 +251,20 @@ class NativeModel:
         ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         check(self.lib.mi_op_tp_all_reduce(self._ctx, ptrs, n))
 
+    def tp_info(self) -> dict:
+        """What the in-process tensor-parallel group runs on (mi_tp_info): transport in use, self-test, devices, peer
+        access, whether the step replays from hipGraphs, loopback mode."""
+        info = MiTpInfo()
+        check(self.lib.mi_tp_info(self._ctx, C.byref(info)))
+        T = info.tp_degree
+        return {"tp_degree": T, "transport_used": {0: "p2p", 1: "rccl"}[info.transport],
+                "selftest": {1: "passed", 0: "not run", -1: "p2p failed, rccl passed", -2: "failed"}[info.selftest],
+                "graphs": bool(info.graphs),
+                "mode": {0: "one GPU per rank", 1: "single-GPU loopback, lockstep (one stream, host barriers)",
+                         2: "single-GPU loopback, concurrent streams (device flag waits)"}[info.mode],
+                "timeout_ms": info.timeout_ms, "device_ids": list(info.device_ids[:T]),
+                "peer_access": [[bool(info.peer_access[r] >> p & 1) for p in range(T)] for r in range(T)]}
+
     def set_num_blocks(self, num_blocks: int) -> None:
         check(self.lib.mi_set_num_blocks(self._ctx, num_blocks))
         self.cfg.num_blocks = num_blocks

@@ -66,6 +66,7 @@ struct mi_group {
   int T = 0;
   bool same_device = false;              // every shard on ONE device (single-GPU loopback)
   bool lockstep = false;                 // ... with a shared stream and host barriers between the exchange kernels (the default loopback form)
+  bool host_barrier = false;             // concurrent loopback with a host barrier between publish and reduce (eager launches)
   int selftest = 0;                      // 1 passed, -1 peer-memory exchange failed (RCCL took over), -2 both failed, 0 not run
   int device_ids[16] = {0};
   int peer_access[16] = {0};             // bit p of word r: rank r's device maps rank p's memory

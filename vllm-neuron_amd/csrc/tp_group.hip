@@ -365,6 +365,13 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
   // device flags exactly as they will across GPUs (the waits are bounded, so a scheduling problem is a failed call, not a hang).
   const bool concurrent = same && getenv("MI355X_TP_LOOPBACK_CONCURRENT") && getenv("MI355X_TP_LOOPBACK_CONCURRENT")[0] == '1';
   g->lockstep = same && !concurrent;
+  // Measured on one MI355X (tools/tp_concurrent_probe.py): two shard streams run side by side, and the exchange passes its
+  // self-test and the model tests from hipGraphs; with four or eight, a reduce kernel that waits on a flag ends up IN FRONT of
+  // the publish kernel it waits for in one of the device's hardware queues (whatever GPU_MAX_HW_QUEUES says) and the wait runs
+  // into its time bound -- a property of several dependent streams on ONE device, not of the protocol: with every publish
+  // enqueued before any reduce (MI355X_TP_CONCURRENT_HOSTBAR=1: a host barrier between the two launches, hence eager launches)
+  // four and eight concurrent shard streams pass.  On a node every rank has a device, and queues, of its own.
+  g->host_barrier = concurrent && getenv("MI355X_TP_CONCURRENT_HOSTBAR") != nullptr;
   g->use_rccl = (!same && cfg.tp_transport == MI_TP_TRANSPORT_RCCL) ? 1 : 0;
   for (int r = 0; r < T; ++r) { g->device_ids[r] = cfg.tp_device_ids[r]; g->peer_access[r] = same ? (1 << T) - 1 : (1 << r); }
   g->bar = new HostBarrier(T);
@@ -401,7 +408,7 @@ int group_create(const mi_model_config& cfg, mi_ctx* facade) {
     mi_model_config k = cfg;
     k.tp_rank = r;
     k.device_id = cfg.tp_device_ids[r];
-    if (g->lockstep) k.use_graphs = 0;   // host barriers sit between the exchange kernels
+    if (g->lockstep || g->host_barrier) k.use_graphs = 0;   // host barriers sit between the exchange kernels
     if (g->use_rccl) k.use_graphs = 0;   // ncclAllReduce under stream capture on T threads at once: never run anywhere, so not relied on
     mi_ctx* c = nullptr;
     int rc2 = mi_ctx_create(&k, &c);
@@ -546,9 +553,13 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
   ge.G = (int)std::min<unsigned>(kArMaxBlocks, std::max<unsigned>(1, ceil_div((int)ge.chunks, kArThreads)));
   ge.cpw = (ge.chunks + ge.G - 1) / ge.G;
   ge.pubG = ge.G;
-  if (two_shot) hipLaunchKernelGGL(ar_publish_kernel<false>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
+  // test hook (tests/test_tp_group_gpu.py: a peer that never publishes): rank MI355X_TP_TEST_MUTE_RANK skips its publish
+  const char* mute = getenv("MI355X_TP_TEST_MUTE_RANK");
+  if (mute && atoi(mute) == r) {
+  } else if (two_shot) hipLaunchKernelGGL(ar_publish_kernel<false>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
   else hipLaunchKernelGGL(ar_publish_kernel<true>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
-  if (g->lockstep) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");   // every rank's publish is in the stream
+  const bool hostbar = g->host_barrier;   // concurrent loopback beyond two shards: every publish enqueued before any reduce (group_create)
+  if (g->lockstep || hostbar) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");   // every rank's publish is in the stream
   if (!two_shot) {
     hipLaunchKernelGGL(ar_reduce_kernel<true>, dim3(ge.G), dim3(kArThreads), 0, s, buf, g->peers, ge, ctr);
   } else {
@@ -557,7 +568,7 @@ int group_all_reduce(mi_ctx* c, float* buf, size_t count) {
     g2.G = (int)std::min<unsigned>(kArMaxBlocks, std::max<unsigned>(1, ceil_div((int)g2.cps, kArThreads)));
     g2.cpw = (g2.cps + g2.G - 1) / g2.G;
     hipLaunchKernelGGL(ar_reduce_scatter_kernel, dim3(g2.G), dim3(kArThreads), 0, s, buf, g->peers, g2, ctr);
-    if (g->lockstep) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
+    if (g->lockstep || hostbar) MI_CHECK(g->bar->wait(), "tensor-parallel group aborted");
     hipLaunchKernelGGL(ar_gather_kernel, dim3(g2.G), dim3(kArThreads), 0, s, buf, g->peers, g2, ctr);
   }
   MI_HIP(hipGetLastError());
