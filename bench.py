@@ -24,7 +24,12 @@ What the line says, key by key:
                                activations: what the reference's quantized linears compute -- the
                                parity path).
   ttft_p50_ms_fp8_activations  the fast mode (per-token FP8 activations on the MX-scaled MFMA) and
-  fp8_activation_first_token_agreement   how often its greedy first token equals the parity path's.
+  fp8_activation_first_token_agreement   how often its greedy first token equals the parity path's (all prompts);
+  fp8_activation_agreement_gated         the same over the prompts whose weight-only top-2 logit gap exceeds the mode's own
+                               logit noise (how many qualify, the rms between the modes' logits): what the MODE does,
+                               not what near-tied random weights do.
+  tp                           (--gpus N) what the tensor-parallel group ran on: transport in use, self-test, devices,
+                               peer access, hipGraphs, loopback mode (mi_tp_info).
   roofline                     the weight-streaming GEMV (dominant kernel): algorithmic weight bytes
                                per launch / average launch duration.  The duration is measured live:
                                the GEMV launches of a step replayed back to back in a graph of their
@@ -362,13 +367,44 @@ def main():
             first[str(bucket)] = toks[1:]
             print(f"[bench] ttft {tag} bucket {bucket}: {[round(x, 2) for x in samples]} ms", file=sys.stderr, flush=True)
         return res, first
+    ttft_a8, agreement, agreement_gated = None, None, None
+    eng2 = make_engine(True) if wd == "f8e4m3" else None
+    if eng2 is not None:
+        # ---- does the FP8 x FP8 mode keep the greedy token?  Measured on the LOGITS of both modes for the same prompts, before
+        #      any engine call (the pools are still unhashed, so writing blocks 1.. by hand disturbs nothing): a prompt only says
+        #      something about the mode when the weight-only top-2 gap is larger than the mode's own logit noise on that prompt
+        #      (on N(0, 0.02) weights the gap is usually far below it, and an ungated rate measures the weights).
+        from tests.helpers import prefill_inputs
+        native2 = eng2.worker.model_runner.model.model
+        ga = torch.Generator().manual_seed(0)
+        blocks_a = list(range(1, MAX_MODEL_LEN // BLOCK_SIZE + 1))
+        agreement, agreement_gated = {}, {}
+        for bucket in BUCKETS:
+            same, qual, qual_same, rms_all, gap_all = 0, 0, 0, [], []
+            for _ in range(args.ttft_prompts):
+                prompt = torch.randint(0, hf.vocab_size, (bucket - 17,), generator=ga).tolist()
+                inp = prefill_inputs(prompt, blocks_a, BLOCK_SIZE, MAX_MODEL_LEN, 0)
+                lw = native.forward(**inp)[0].double()
+                la = native2.forward(**inp)[0].double()
+                top2 = torch.topk(lw, 2).values
+                gap = float(top2[0] - top2[1])
+                rms = float((la - lw).pow(2).mean().sqrt())
+                eq = int(lw.argmax()) == int(la.argmax())
+                same += eq
+                if gap > 2.0 * rms:          # a 2-sigma rule on the difference of two noisy logits
+                    qual += 1
+                    qual_same += eq
+                rms_all.append(rms)
+                gap_all.append(gap)
+            n = args.ttft_prompts
+            agreement[str(bucket)] = round(same / n, 3)
+            agreement_gated[str(bucket)] = {
+                "prompts": n, "qualifying": qual, "agreement_over_qualifying": round(qual_same / qual, 3) if qual else None,
+                "logit_rms_between_modes": round(statistics.median(rms_all), 4), "median_weight_only_top2_gap": round(statistics.median(gap_all), 4),
+                "logit_std": round(float(lw.std()), 3)}
     ttft, first_wo = ttft_sweep(eng, "weight-only")
-    ttft_a8, agreement = None, None
-    if wd == "f8e4m3":
-        eng2 = make_engine(True)
+    if eng2 is not None:
         ttft_a8, first_a8 = ttft_sweep(eng2, "fp8xfp8")
-        agreement = {b: round(sum(x == y for x, y in zip(first_wo[b], first_a8[b])) / max(len(first_wo[b]), 1), 3)
-                     for b in first_wo}
         eng2.worker.model_runner.model.model.close()
         del eng2
 
@@ -557,6 +593,9 @@ def main():
         "engine_decode_tokens_per_s_chunked_prefill_scheduler": engine_chunked,
         "ttft_p50_ms": ttft, "ttft_mode": "weight-only quantization (the parity path)",
         "ttft_p50_ms_fp8_activations": ttft_a8, "fp8_activation_first_token_agreement": agreement,
+        "fp8_activation_agreement_gated": ({"rule": "a prompt qualifies when the weight-only top-2 logit gap exceeds 2 x the rms of "
+                                            "(FP8 x FP8 logits - weight-only logits) over its vocabulary row", "per_bucket": agreement_gated}
+                                           if agreement_gated else None),
         "ttft_frac_of_mfma_peak": ttft_frac,
         "prefix_cache_ttft_ms": prefix_ttft,
         "device_ms_per_step": round(dev_ms / args.steps, 4),
@@ -565,6 +604,13 @@ def main():
         "speculation": speculation,
         "init_s": round(init_s, 2), "roofline": roofline, "cpu_baseline": cpu,
     }
+    if tp > 1:
+        # what the tensor-parallel group actually ran on: "N ranks over peer memory, in hipGraphs" and
+        # "fell back to RCCL, eager" must be told apart in a SCALE record
+        try:
+            line["tp"] = native.tp_info()
+        except Exception as ex:                                   # noqa: BLE001 -- the bench line must still be printed
+            line["tp"] = {"error": str(ex)}
     finish(line)
 
 
