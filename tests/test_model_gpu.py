@@ -131,7 +131,11 @@ def test_prefill_fp8_activations_matches_oracle(name):
     """Context-encoding GEMMs with per-token FP8 activations on the MX-scaled MFMA vs the oracle's
     statement of the same rule (rows > 16, K % 128 == 0, fp8 weights).  fp8 activations carry a
     3-bit mantissa, so a borderline rounding of one activation moves a logit more than in the
-    bf16 path: tolerance 0.12 on O(4) logits, ids compared where the oracle's gap > 0.3."""
+    bf16 path: tolerance 0.15 on O(4) logits, ids compared where the oracle's gap > 0.3.  (0.12 until
+    round 3: the second-generation context-encoding attention sums in another order and defers the
+    softmax rescale -- its own op test holds the same 0.03 against an fp64 reference as the first
+    kernel -- and on the head_dim-64 model one activation now rounds to the neighbouring fp8 code:
+    0.1215 against 0.11 before.  The weight-only parity tests keep their 0.06.)"""
     cfg = zoo_config(name)
     w = make_weights(cfg, seed=1)
     gen, _, _ = load_golden(name)
@@ -152,7 +156,7 @@ def test_prefill_fp8_activations_matches_oracle(name):
             top2 = ref[r].topk(2).values
             if top2[0] - top2[1] > 0.3:
                 assert int(got[r].argmax()) == int(ref[r].argmax()), (kind, req, step)
-    assert worst < 0.12, worst
+    assert worst < 0.15, worst
     assert moved > 0.01, "the FP8-activation rule never fired: the test is not testing it"
     model.close()
 
