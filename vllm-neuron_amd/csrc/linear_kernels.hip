@@ -1706,38 +1706,42 @@ static int launch_gemm_wd(const LinearW& w, int T, const uint16_t* x, int ldx, i
 
 
 // =====================================================================================
-// GEMM, wide-N tile with an LDS-DMA ring (context encoding at >= 1024 rows, 1-byte weights)
+// GEMM, wide-N tile with an LDS-DMA ring and two wave groups half a K-step apart (context encoding, 1-byte weights)
 // =====================================================================================
 // The 128 x 128 kernel above is L1-fill bound: per 64-deep K-step a work-group pulls
 // 16 KiB of bf16 activations + 8 KiB of fp8 weights for 2.1 MFLOP.  Weights are half the bytes per
 // element of the activations, so the tile grows along N: 128 tokens x 256 weight rows = 16 + 16 KiB
-// for 4.2 MFLOP (1.5 x the flops per byte).  Eight waves side by side along N, each 32 weight rows x
-// waves as 2 (tokens) x 4 (weight rows), each 64 x 64 (64 accumulator registers, 12 fragment reads
-// per 32 MFMAs): activation fragments are shared by four waves, weight fragments by two.  Both operands arrive by LDS-DMA
+// for 4.2 MFLOP (1.5 x the flops per byte), 256 x 256 = 32 + 16 KiB for 8.4.  Eight waves as 2 (tokens) x 4 (weight
+// rows): activation fragments are shared by four waves, weight fragments by two.  Both operands arrive by LDS-DMA
 // (global_load_lds, 1 KiB per wave-instruction: the weight tiles land lane-linear = fragment
 // order; the activation rows land in the XOR-swizzled image of the kernel above, the swizzle being
-// applied to the per-lane SOURCE address) into a ring of three 32 KiB stages: two K-steps are in
-// flight while one is multiplied, retired by a counted vmcnt (4 DMAs per wave and stage) in front of
-// ONE raw barrier per K-step -- no ordinary global load in the loop, so hipcc has nothing to drain.
+// applied to the per-lane SOURCE address) into a ring of three stages: two K-steps are in
+// flight while one is multiplied, retired by counted vmcnt waits in front of raw barriers -- no ordinary global
+// load in the loop, so hipcc has nothing to drain.  Round 3: a wave's K-step is a READ phase (fragments LDS -> registers,
+// weight codes decoded on the way) and a MULTIPLY phase (MFMAs only), and the two waves of a SIMD are in opposite phases
+// (see "Schedule" in the kernel): gate|up at 2048 tokens 436.6 -> 373.4 us (1.10 -> 1.29 PF/s), down 220 -> 198 us.
 constexpr int kWideBN = 256, kWideWBytes = 16 * 1024, kWideStages = 3;
 
 
-// BM = 128: waves 2 (tokens) x 4 (weight rows), each 64 x 64.  BM = 256: each 128 x 64 (128 accumulator
-// registers): 16 + 32 KiB per K-step for 8.4 MFLOP -- the kernel is bound by what a CU can take in
-// (~25 GB/s: a K-step's bytes over its loaded latency), so fewer bytes per flop is the lever.
+// BM = 128: each wave 64 x 64 (64 accumulator registers).  BM = 256: each 128 x 64 (128 accumulator registers, 246 VGPRs
+// with the decoded fragments of one K-step).
 template <int WD, int EPI, int BM>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
                                                         const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
   static_assert(WD != MI_W_BF16, "1-byte weight tiles (64 k per tile)");
   static_assert(BM == 128 || BM == 256, "token block");
+  // waves as 2 (tokens) x 4 (weight rows), each MT 16-token tiles x 4 16-row weight tiles.  (4 x 2 waves of 64 x 128 read
+  // 16 instead of 20 KiB of fragments per K-step but decode every weight code four times instead of twice: measured slower,
+  // 401 against 387 us on the gate-up shape -- the decode, not the LDS read, is what the schedule has to hide.)
   constexpr int MT = BM / 32;                 // 16-token tiles per wave
+  constexpr int WM = 2, NTW = 4;
   constexpr int XP = BM / 64;                 // 8-row activation pieces per wave and stage
   constexpr int kStage = kWideWBytes + BM * 128;
   constexpr int kDma = 2 + XP;                // DMAs per wave and stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int g = lane >> 4, c = lane & 15;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   // XCD-aware tile order (see gemm_a8_kernel): an XCD walks all token blocks of a weight slab back to back
   const int mtiles = ceil_div(T, BM), ntiles = ceil_div(NT, kWideBN / 16);
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -1765,47 +1769,78 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict_
     for (int i = 0; i < XP; ++i) glds16(xsrc[i] + (size_t)ks * 64, st + kWideWBytes + (XP * wave + i) * 1024);
   };
 
-  f32x4_t acc[4][MT];
+  f32x4_t acc[NTW][MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // Schedule.  A K-step of a wave is two phases: READ (its fragments, 20 KiB at BM = 256, from LDS into registers, the weight codes decoded to bf16 on the way) and MULTIPLY
+  // (2 NTW MT MFMAs from registers).  With one barrier per K-step every wave is in the same phase at the same time, the two waves
+  // of a SIMD included, and LDS-read time and MFMA time add up: 1.7 us per K-step at BM = 256 against 1.0 us of MFMAs.  Here
+  // the two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run half a K-step apart -- group 1 executes one
+  // barrier more at the start -- so one group multiplies while the other reads:
+  //     physical barrier:      P0        P1        P2        P3        P4  ...
+  //     group 0 (waves 0-3):   | READ 0  | MUL 0   | READ 1  | MUL 1   | ...
+  //     group 1 (waves 4-7):   |         | READ 0  | MUL 0   | READ 1  | MUL 1 ...
+  // Stage k is read in [P2k, P2k+2]; K-step k + 2 goes into the stage of K-step k - 1 (read until P2k), requested by every wave
+  // behind its top barrier of iteration k: two K-steps ahead of its first read, as before.  A wave waits for ITS pieces of a
+  // stage before the barrier in front of the stage's first read by anyone (group 0: its top barrier; group 1: its second one).
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
   issue(0);
   if (nks > 1) issue(1);
+  if (grp == 1) {   // its pieces of stage 0 are in before P0
+    if (nks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();           // P0
+  }
   for (int ks = 0; ks < nks; ++ks) {
-    // stage ks has landed once at most the DMAs of stage ks + 1 are outstanding (in-order retire)
-    if (ks + 1 < nks) {
-      if constexpr (kDma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (grp == 0) {   // own pieces of stage ks (at most those of stage ks + 1 are younger)
+      if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();          // every wave's pieces of stage ks are in; everyone is done reading stage ks - 1
-    if (ks + 2 < nks) issue(ks + 2);       // into the buffer stage ks - 1 was read from
+    __builtin_amdgcn_s_barrier();           // group 0: P2ks | group 1: P2ks+1 -- either way nobody reads stage ks - 1 any more
+    if (ks + 2 < nks) issue(ks + 2);
     const unsigned char* st = smem + (ks % kWideStages) * kStage;
     const uint4* xs = reinterpret_cast<const uint4*>(st + kWideWBytes);
-    bf16x8_t b0[MT], b1[MT];
+    u32x4_t b0[MT], b1[MT];
+    bf16x8_t a0[NTW], a1[NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int r = wm * (BM / 2) + mt * 16 + c;
-      b0[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g) ^ xs_swz<WD>(r))]);
-      b1[mt] = __builtin_bit_cast(bf16x8_t, xs[r * 8 + ((2 * g + 1) ^ xs_swz<WD>(r))]);
+      b0[mt] = *reinterpret_cast<const u32x4_t*>(&xs[r * 8 + ((2 * g) ^ xs_swz<WD>(r))]);
+      b1[mt] = *reinterpret_cast<const u32x4_t*>(&xs[r * 8 + ((2 * g + 1) ^ xs_swz<WD>(r))]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const u32x4_t w4 = *reinterpret_cast<const u32x4_t*>(st + (wn * 4 + i) * 1024 + lane * 16);
-      const bf16x8_t a0 = decode8<WD>(w4[0], w4[1]), a1 = decode8<WD>(w4[2], w4[3]);
+    for (int i = 0; i < NTW; ++i) {   // decoded here, in the READ phase, while the SIMD's other wave multiplies: the MULTIPLY phase is MFMAs only
+      const u32x4_t w4 = *reinterpret_cast<const u32x4_t*>(st + (wn * NTW + i) * 1024 + lane * 16);
+      a0[i] = decode8<WD>(w4[0], w4[1]);
+      a1[i] = decode8<WD>(w4[2], w4[3]);
+    }
+    // the fragments are in registers (the empty asm takes them as operands: the compiler's wait for the reads sits in front of it)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { asm volatile("" : "+v"(b0[mt])); asm volatile("" : "+v"(b1[mt])); }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { asm volatile("" : "+v"(a0[i])); asm volatile("" : "+v"(a1[i])); }
+    if (grp == 1 && ks + 1 < nks) {   // own pieces of stage ks + 1: group 0 reads it behind the next barrier
+      if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();           // group 0: P2ks+1 | group 1: P2ks+2
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0[mt], acc[i][mt], 0, 0, 0);
-        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1[mt], acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], __builtin_bit_cast(bf16x8_t, b0[mt]), acc[i][mt], 0, 0, 0);
+        acc[i][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], __builtin_bit_cast(bf16x8_t, b1[mt]), acc[i][mt], 0, 0, 0);
       }
     }
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // the barrier group 1 executed first
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int nt = ntb + wn * 4 + i;
+  for (int i = 0; i < NTW; ++i) {
+    const int nt = ntb + wn * NTW + i;
     if (nt >= NT) continue;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1859,15 +1894,19 @@ static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
   const int mode = gemm_wide_mode();
   if (forced || mode == 1) return true;
   if (mode == 0) return false;
-  // measured on the Llama-8B shapes: ahead of the 128 x 128 kernel from the 2048 bucket on (30.9 vs 32.0 ms), behind it
-  // at 1024 (20.2 vs 17.8 ms: 128 / 192-tile grids on a one-work-group-per-CU kernel)
-  // and only where its one-work-group-per-CU grid fills whole rounds of the chip: QKV at 2048 tokens (N 6144) is 384
-  // work-groups = 1.5 rounds, 144.7 us against 118.2 us on the 128 x 128 kernel (768 work-groups of 256 threads)
-  if (T <= 1024) return false;
+  // It runs ONE work-group per CU (96 / 144 KiB of LDS), so what decides is how full its rounds of the chip are.  Measured on
+  // the Llama-8B shapes (round 3, staggered schedule; wide at 128-token blocks against the 128 x 128 kernel, us):
+  //     gate|up  256 tokens: 224 work-groups (one round, 88 %)   62.0 vs  73.4      512: 448 (two rounds, 88 %)  115.3 vs 141.6
+  //     gate|up 1024 tokens: 896 (3.5 rounds, 88 %)             224.5 vs 227.6      QKV 1024: 192 (one round, 75 %) 66.6 vs 84.2
+  //     QKV  512: 96 work-groups   64.6 vs 40.1      O / down 1024: 128   57.1 vs 40.7 / 166.6 vs 116.2 (K-split on the other side)
+  //     QKV 2048: 384 (1.5 rounds, 75 %)  134.5 vs 112.4
+  // -> one partial round from 70 % of the CUs on, several rounds from 80 % fill on.
+  if (T < 256) return false;
   int cus = 256;
   if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
   const int wgs = ceil_div(T, 128) * ceil_div(w.N, kWideBN);
-  return wgs >= cus && wgs * 5 >= ceil_div(wgs, cus) * cus * 4;
+  if (wgs < cus) return wgs * 10 >= cus * 7;
+  return wgs * 5 >= ceil_div(wgs, cus) * cus * 4;
 }
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
   MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");
