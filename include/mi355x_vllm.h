@@ -291,6 +291,12 @@ int mi_op_tp_all_reduce(mi_ctx* ctx, float* const* bufs, size_t count);
  * [B, 3] fp32 (top_k, top_p, temperature) or NULL = greedy, tokens_out [B] int32 -- all device. */
 int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
                  int32_t* tokens_out, void* stream);
+/* The same with the engine's scratch buffer (mi_op_sample_scratch_bytes(B) bytes of device memory): the form
+ * mi_forward_tokens runs -- all-greedy batches split the argmax over the chip, top-k / top-p rows have the
+ * vocabulary pre-selected by 32 work-groups per row.  Same ids as mi_op_sample. */
+size_t mi_op_sample_scratch_bytes(int32_t B);
+int mi_op_sample_ws(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
+                    int32_t* tokens_out, void* scratch, size_t scratch_bytes, void* stream);
 
 
 /* Quantize + re-tile a row-major fp32 [N, K] device matrix.  scale_out [N] fp32.

@@ -19,16 +19,30 @@ from tests.test_model_gpu import load_golden, native_model, scenario
 pytestmark = pytest.mark.gpu
 
 
-def _op_sample(logits, params, seed):
+def _op_sample_one(logits, params, seed, ws):
     from vllm_neuron_amd import _native
+    L = _native.load_library()
     B, V = logits.shape
     ld = logits.cuda()
     pd = params.cuda() if params is not None else None
     out = torch.empty(B, dtype=torch.int32, device="cuda")
-    _native.check(_native.load_library().mi_op_sample(ld.data_ptr(), B, V, pd.data_ptr() if pd is not None else None,
-                                                      seed, out.data_ptr(), None))
+    if ws:   # the engine's form: with the scratch buffer the vocabulary is pre-selected by 32 work-groups per row
+        nb = L.mi_op_sample_scratch_bytes(B)
+        scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        _native.check(L.mi_op_sample_ws(ld.data_ptr(), B, V, pd.data_ptr() if pd is not None else None, seed, out.data_ptr(),
+                                        scratch.data_ptr(), nb, None))
+    else:
+        _native.check(L.mi_op_sample(ld.data_ptr(), B, V, pd.data_ptr() if pd is not None else None, seed, out.data_ptr(), None))
     torch.cuda.synchronize()
     return out.cpu().tolist()
+
+
+def _op_sample(logits, params, seed):
+    """Both forms of the sampler (one work-group per row / the engine's, spread over the chip): they must give the same ids."""
+    a = _op_sample_one(logits, params, seed, False)
+    b = _op_sample_one(logits, params, seed, True)
+    assert a == b, (a, b)
+    return a
 
 
 def _agrees(logits_row, tk, tp, tt, seed, row, got):
@@ -108,6 +122,32 @@ def test_mass_ties_at_the_threshold_never_evict_larger_logits(V):
         assert got == _op_sample(logits, params, seed)               # deterministic
         seen.add(got[0])
     assert seen & set(big.tolist())                                   # the large logits are drawn (they carry ~45 % of the mass)
+
+
+@pytest.mark.parametrize("V", [8192, 20011, 128256, 262144])
+def test_spread_sampler_edge_rows(V):
+    """The chip-wide form on rows that stress the slice pre-selection: ties that straddle slice boundaries, a row whose
+    finite logits are fewer than top_k (the rest -inf), the whole mass in the last slice, per-row top_k from 1 to 256."""
+    g = torch.Generator().manual_seed(11 + V)
+    per = -(-V // 32)
+    logits = torch.randn(6, V, generator=g) * 2.0
+    logits[0, per - 3:per + 3] = 9.0                       # six equal maxima across the first slice boundary
+    logits[0, 5 * per - 1] = 9.0
+    logits[1] = float("-inf")
+    logits[1, torch.randperm(V, generator=g)[:7]] = torch.randn(7, generator=g)   # 7 finite words, top_k 40
+    logits[2] = -30.0
+    logits[2, V - 300:] = torch.randn(300, generator=g)    # everything that matters in the last slice
+    logits[3, ::per] = 4.0                                 # one equal candidate at the head of every slice
+    params = torch.tensor([[4.0, 1.0, 1.0], [40.0, 1.0, 1.0], [256.0, 0.95, 0.9], [20.0, 1.0, 1.2], [1.0, 1.0, 1.0], [100.0, 0.8, 0.7]])
+    bad = []
+    for seed in range(25):
+        got = _op_sample(logits, params, seed)
+        for row in range(6):
+            tk, tp, tt = params[row].tolist()
+            if not _agrees(logits[row].numpy(), int(tk), tp, tt, seed, row, got[row]):
+                bad.append((seed, row, got[row]))
+    assert not bad, bad[:5]
+    assert _op_sample(logits, None, 0) == logits.argmax(dim=1).tolist()
 
 
 def test_empirical_distribution_matches_the_nucleus():

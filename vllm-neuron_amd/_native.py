@@ -106,6 +106,8 @@ _SIGS = {
     "mi_tp_info": (C.c_int, [C.c_void_p, C.POINTER(MiTpInfo)]),
     "mi_op_tp_all_reduce": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "mi_op_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mi_op_sample_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "mi_op_sample_ws": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mi_op_quantize_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi_op_untile_weight": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -1879,34 +1879,44 @@ static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int l
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
+// The wide kernel runs ONE work-group per CU (96 / 144 KiB of LDS), so what decides is how full its rounds of the chip are,
+// and between the two token blocks, rounds x time per K-step (measured on full grids: 0.90 us at 128 tokens, 1.45 us at 256 --
+// twice the flops).  Measured on the Llama-8B shapes (round 3, staggered schedule; wide against the 128 x 128 kernel, us):
+//     gate|up  256 tokens: 224 work-groups of 128 tokens (one round, 88 %)   62.0 vs  73.4      512: 448 (two rounds)  115.3 vs 141.6
+//     gate|up 1024 tokens: 896 (3.5 rounds)                                 224.5 vs 227.6      QKV 1024: 192 (one round, 75 %) 66.6 vs 84.2
+//     QKV  512: 96 work-groups   64.6 vs 40.1      O / down 1024: 128   57.1 vs 40.7 / 166.6 vs 116.2 (K-split on the other side)
+//     QKV 2048: 384 (1.5 rounds, 75 %)  134.5 vs 112.4;  gate|up 2048: 403.6 at 128 tokens (7 rounds), 373.4 at 256 (3.5)
+// -> a block size is eligible with one partial round from 70 % of the CUs on or several rounds at 80 % fill; the cheaper eligible one runs.
+struct WidePlan { int bm; };   // 0: not wanted
+static WidePlan gemm_wide_plan(int T, int N) {
+  int cus = 256;
+  if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
+  WidePlan best{0};
+  int best_cost = 0;
+  for (int bm = 128; bm <= 256; bm *= 2) {
+    const int wgs = ceil_div(T, bm) * ceil_div(N, kWideBN), rounds = ceil_div(wgs, cus);
+    const bool ok = wgs < cus ? wgs * 10 >= cus * 7 : wgs * 5 >= rounds * cus * 4;
+    const int cost = rounds * (bm == 128 ? 90 : 145);
+    if (ok && (best.bm == 0 || cost < best_cost)) { best.bm = bm; best_cost = cost; }
+  }
+  return best;
+}
 template <int WD>
 static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
-  // 256-token blocks when that still gives every CU at least two work-groups to walk (the grid
-  // is one resident wave of work-groups per CU at a time)
-  const int forced = gemm_wide_bm();
-  const bool big = forced ? forced == 256 : ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512;
-  if (big) return launch_gemm_wide_bm<WD, 256>(w, T, x, ldx, epi, e, s);
+  int bm = gemm_wide_bm();
+  if (bm != 128 && bm != 256) bm = gemm_wide_plan(T, w.N).bm;
+  if (bm == 0) bm = ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512 ? 256 : 128;   // forced onto a shape the plan would not take
+  if (bm == 256) return launch_gemm_wide_bm<WD, 256>(w, T, x, ldx, epi, e, s);
   return launch_gemm_wide_bm<WD, 128>(w, T, x, ldx, epi, e, s);
 }
-// the wide tile needs 1-byte weights and enough tiles to give every CU one (it runs one work-group per CU)
+// the wide tile needs 1-byte weights
 static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
   if (w.wd == MI_W_BF16 || w.K % 64 != 0 || (w.N / 16) < 2) return false;
   const int mode = gemm_wide_mode();
   if (forced || mode == 1) return true;
   if (mode == 0) return false;
-  // It runs ONE work-group per CU (96 / 144 KiB of LDS), so what decides is how full its rounds of the chip are.  Measured on
-  // the Llama-8B shapes (round 3, staggered schedule; wide at 128-token blocks against the 128 x 128 kernel, us):
-  //     gate|up  256 tokens: 224 work-groups (one round, 88 %)   62.0 vs  73.4      512: 448 (two rounds, 88 %)  115.3 vs 141.6
-  //     gate|up 1024 tokens: 896 (3.5 rounds, 88 %)             224.5 vs 227.6      QKV 1024: 192 (one round, 75 %) 66.6 vs 84.2
-  //     QKV  512: 96 work-groups   64.6 vs 40.1      O / down 1024: 128   57.1 vs 40.7 / 166.6 vs 116.2 (K-split on the other side)
-  //     QKV 2048: 384 (1.5 rounds, 75 %)  134.5 vs 112.4
-  // -> one partial round from 70 % of the CUs on, several rounds from 80 % fill on.
   if (T < 256) return false;
-  int cus = 256;
-  if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
-  const int wgs = ceil_div(T, 128) * ceil_div(w.N, kWideBN);
-  if (wgs < cus) return wgs * 10 >= cus * 7;
-  return wgs * 5 >= ceil_div(wgs, cus) * cus * 4;
+  return gemm_wide_plan(T, w.N).bm != 0;
 }
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
   MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");

@@ -1718,6 +1718,13 @@ int mi_op_sample(const float* logits, int32_t B, int32_t V, const float* samplin
   MI_CHECK(logits && tokens_out && B >= 1 && V >= 1, "bad argument");
   return launch_sample_rows(logits, 1, B, V, B, sampling_params, seed, 0, tokens_out, (hipStream_t)stream);
 }
+size_t mi_op_sample_scratch_bytes(int32_t B) { return B >= 1 ? sample_scratch_bytes(B) : 0; }
+int mi_op_sample_ws(const float* logits, int32_t B, int32_t V, const float* sampling_params, uint64_t seed,
+                    int32_t* tokens_out, void* scratch, size_t scratch_bytes, void* stream) {
+  MI_CHECK(logits && tokens_out && B >= 1 && V >= 1, "bad argument");
+  MI_CHECK(scratch && scratch_bytes >= sample_scratch_bytes(B), "mi_op_sample_ws: scratch smaller than mi_op_sample_scratch_bytes(B)");
+  return launch_sample_rows(logits, 1, B, V, B, sampling_params, seed, 0, tokens_out, (hipStream_t)stream, scratch);
+}
 
 int mi_op_quantize_weight(const float* w, int32_t N, int32_t K, int32_t wd, int32_t qt, void* tiled_out,
                           float* scale_out, void* stream) {
