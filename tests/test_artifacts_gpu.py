@@ -107,7 +107,7 @@ def test_plugin_builds_and_reuses_the_artifact_directory(tmp_path):
         return toks, info
 
     toks1, (hit1, dir1) = run(q)
-    assert not hit1 and dir1.startswith(str(ckpt / "mi355x-compiled-artifacts")) and os.listdir(dir1) == ["rank0_of1.miw"]
+    assert not hit1 and dir1.startswith(str(ckpt / "mi355x-compiled-artifacts")) and sorted(os.listdir(dir1)) == ["checkpoint.json", "rank0_of1.miw"]
     # second start: the checkpoint's tensors are not needed any more
     st = os.stat(ckpt / "model.safetensors")
     (ckpt / "model.safetensors").write_bytes(b"")
@@ -124,3 +124,14 @@ def test_plugin_builds_and_reuses_the_artifact_directory(tmp_path):
     assert not hit3 and dir3 == str(explicit) and toks3 == toks1
     toks4, (hit4, _) = run(dict(q, quantized_checkpoints_path=str(explicit), state_dict={}), model="")
     assert hit4 and toks4 == toks1
+    # ... but another checkpoint of the same shape must not pick it up silently: rebuilt from the weights at hand
+    other = make_weights(cfg, 2)
+    toks5, (hit5, dir5) = run(dict(q, quantized_checkpoints_path=str(explicit), state_dict=other), model="")
+    assert not hit5 and dir5 == str(explicit) and toks5 != toks1
+    toks6, (hit6, _) = run(dict(q, quantized_checkpoints_path=str(explicit), state_dict=other), model="")
+    assert hit6 and toks6 == toks5
+    # a directory that cannot be written does not fail the start (the weights are resident already)
+    blocked = tmp_path / "blocked"
+    blocked.write_text("a file where the directory should go")
+    toks7, (hit7, dir7) = run(dict(q, quantized_checkpoints_path=str(blocked), state_dict=make_weights(cfg, 1)), model="")
+    assert not hit7 and dir7 is None and toks7 == toks1

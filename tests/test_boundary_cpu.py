@@ -859,6 +859,32 @@ def test_artifact_directory_rules(tmp_path, monkeypatch):       # reference load
     assert f(str(tmp_path / "missing"), {}, geo, True, "f8e4m3", "per_channel_symmetric", 1) is None
 
 
+def test_artifact_checkpoint_identity(tmp_path):                # base / instruct of one shape must not share artifacts
+    cls = loader.MI355XCausalLM
+    ident = cls._checkpoint_identity
+    assert ident("", {"state_dict": {}}) is None                                   # nothing to compare with: the artifacts are all there is
+    a = {"w": torch.arange(8, dtype=torch.float32).reshape(2, 4)}
+    b = {"w": torch.arange(8, dtype=torch.float32).reshape(2, 4) + 1}
+    assert ident("", {"state_dict": a}) == ident("", {"state_dict": {"w": a["w"].clone()}}) != ident("", {"state_dict": b})
+    assert ident("", {"synthetic_weights": {"seed": 3}}) != ident("", {"synthetic_weights": {"seed": 4}})
+    ckpt = tmp_path / "ckpt"
+    ckpt.mkdir()
+    (ckpt / "model.safetensors").write_bytes(b"x" * 10)
+    i1 = ident(str(ckpt), {})
+    (ckpt / "model.safetensors").write_bytes(b"x" * 11)
+    assert i1 != ident(str(ckpt), {}) and i1["files"][0][:2] == ["model.safetensors", 10]
+    art = tmp_path / "art"
+    cls._check_artifact_identity(str(art), i1)                                      # no directory yet: load_artifacts reports that
+    art.mkdir()
+    with pytest.raises(ValueError, match="does not say"):
+        cls._check_artifact_identity(str(art), i1)
+    cls._write_artifact_identity(str(art), i1)
+    cls._check_artifact_identity(str(art), i1)
+    cls._check_artifact_identity(str(art), None)
+    with pytest.raises(ValueError, match="another checkpoint"):
+        cls._check_artifact_identity(str(art), ident(str(ckpt), {}))
+
+
 def test_update_states_resume_after_preemption_and_kv_init():   # reference test_model_runner.py:823-873 (complex), :569-590
     r = make_runner()
     r.execute_model(sched_out([new_req("a", [1, 2, 3], [4, 5])]))

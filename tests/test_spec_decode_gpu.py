@@ -210,8 +210,9 @@ def test_fused_speculation_window_clipped_at_max_model_len_and_block_boundary():
     blocks2 = [[20, 21, 22, 23, 24, 25, 26, 27]]
     want = _plain_greedy(target, [p], blocks2, len(seq))
     assert seq == want[0]
-    draft.close()
+    # the draft runs on the target's stream: closing the target first must leave the draft closable
     target.close()
+    draft.close()
 
 
 # ---- the whole plugin path: MI355XEngine(speculative_config=...) ---------------------------------

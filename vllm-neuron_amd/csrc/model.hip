@@ -652,7 +652,6 @@ int mi_ctx_create(const mi_model_config* cfg, mi_ctx** out) {
   c->cfg = k;
   if (c->cfg.tp_rank < 0) c->cfg.tp_rank = 0;   // MI_TP_ALL_RANKS of one rank
   MI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  const int T = k.tp_degree;
   c->H = k.hidden_size;
   c->hd = k.head_dim;
   // Head sharding.  kv heads >= ranks: whole kv groups per rank.  Fewer kv heads than ranks: every kv head is
@@ -704,7 +703,10 @@ int mi_ctx_destroy(mi_ctx* c) {
   }
   g_ht.report();
   hipSetDevice(c->cfg.device_id);
-  hipStreamSynchronize(c->stream);
+  // a borrowed stream (a draft model runs on its target's shard-0 stream, mi_forward_spec) may be gone already when the
+  // target was closed first: wait for the device instead of naming it
+  if (c->stream_owned) hipStreamSynchronize(c->stream);
+  else hipDeviceSynchronize();
   for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->grp && c->grp->lockstep && c->cfg.tp_rank != 0) hipStreamSynchronize(c->stream);
@@ -1461,8 +1463,12 @@ int mi_forward_spec(mi_ctx* t, mi_ctx* d, int32_t B, int32_t k, const int64_t* i
   auto draft_chain = [&]() -> int {
     MI_HIP(hipSetDevice(kt.device_id));
     if (d->stream != t0->stream) {   // one stream for the draft and shard 0: the chain is ordered by enqueue order alone
-      MI_HIP(hipStreamSynchronize(d->stream));
-      if (d->stream_owned) hipStreamDestroy(d->stream);
+      if (d->stream_owned) {
+        MI_HIP(hipStreamSynchronize(d->stream));
+        hipStreamDestroy(d->stream);
+      } else {
+        MI_HIP(hipDeviceSynchronize());   // the stream of an earlier target, possibly closed since
+      }
       d->stream = t0->stream;
       d->stream_owned = false;
     }

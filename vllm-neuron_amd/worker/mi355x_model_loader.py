@@ -325,8 +325,10 @@ class MI355XCausalLM(MI355XModelBase):
         # reference's compiled-artifact directory (loader.py:160-226): try them first; on a miss take
         # the checkpoint the long way (read, quantize, tile) and leave the images for the next start.
         artifacts = self._artifact_dir(model_name_or_path, cfg, geo, quantized, qdtype, qtype, tp_degree)
+        identity = self._checkpoint_identity(model_name_or_path, cfg)
         if artifacts is not None:
             try:
+                self._check_artifact_identity(artifacts, identity)
                 self.model.load_artifacts(artifacts)
                 logger.info("Successfully loaded pre-built weight artifacts from %s", artifacts)
                 self.compiled_artifacts_path, self.loaded_from_artifacts = artifacts, True
@@ -342,9 +344,67 @@ class MI355XCausalLM(MI355XModelBase):
             self._load_safetensors_dir(model_name_or_path)
         self.compiled_artifacts_path, self.loaded_from_artifacts = artifacts, False
         if artifacts is not None:
-            self.model.save_artifacts(artifacts)
-            logger.info("Saved weight artifacts to %s", artifacts)
+            # the weights are resident: a directory that cannot be written (read-only model cache, full disk) costs the
+            # next start its shortcut, not this one its model
+            try:
+                self.model.save_artifacts(artifacts)
+                self._write_artifact_identity(artifacts, identity)
+                logger.info("Saved weight artifacts to %s", artifacts)
+            except (OSError, ValueError, RuntimeError) as e:
+                logger.warning("Could not save weight artifacts under %s (%s); continuing without them", artifacts, e)
+                self.compiled_artifacts_path = None
+                return False, None
         return False, artifacts
+
+    _IDENTITY_FILE = "checkpoint.json"
+
+    @staticmethod
+    def _checkpoint_identity(model_name_or_path, cfg):
+        """What tells one checkpoint of a geometry from another (base / instruct): the safetensors files' names, sizes and
+        mtimes for a local directory; names, shapes and a fingerprint of the leading bytes for an in-memory state dict;
+        the seed for synthetic weights.  None when there is no checkpoint to compare with (the artifacts are all there is)."""
+        import hashlib
+        synthetic, state_dict = cfg.get("synthetic_weights"), cfg.get("state_dict")
+        if synthetic is not None:
+            return {"synthetic": [int(synthetic.get("seed", 1)), float(synthetic.get("std", 0.02))]}
+        if state_dict is not None:
+            if not state_dict:
+                return None
+            h = hashlib.md5()
+            for name in sorted(state_dict):
+                t = state_dict[name]
+                h.update(f"{name}:{tuple(t.shape)}:{t.dtype}".encode())
+                h.update(t.detach().reshape(-1)[:64].to("cpu", torch.float32).numpy().tobytes())
+            return {"state_dict": h.hexdigest()}
+        if model_name_or_path and os.path.isdir(model_name_or_path):
+            files = sorted(glob.glob(os.path.join(model_name_or_path, "*.safetensors")))
+            if files:
+                return {"files": [[os.path.basename(f), os.path.getsize(f), int(os.path.getmtime(f))] for f in files]}
+        return None
+
+    @classmethod
+    def _check_artifact_identity(cls, artifacts, identity) -> None:
+        """ValueError when the directory was built from another checkpoint than the one at hand.  The native header
+        (mi_save_weights) holds geometry, quantization and sharding only."""
+        import json
+        path = os.path.join(artifacts, cls._IDENTITY_FILE)
+        if identity is None or not os.path.isdir(artifacts):
+            return                                # nothing to compare / nothing there (load_artifacts reports the latter)
+        try:
+            with open(path, "r", encoding="utf-8") as f:
+                saved = json.load(f)
+        except FileNotFoundError:
+            raise ValueError(f"{artifacts} does not say which checkpoint it was built from ({cls._IDENTITY_FILE} missing)") from None
+        if saved != identity:
+            raise ValueError(f"{artifacts} was built from another checkpoint of this shape")
+
+    @classmethod
+    def _write_artifact_identity(cls, artifacts, identity) -> None:
+        import json
+        if identity is None:
+            return
+        with open(os.path.join(artifacts, cls._IDENTITY_FILE), "w", encoding="utf-8") as f:
+            json.dump(identity, f)
 
     def _load_draft(self, speculative_config, cfg, num_blocks, block_size, max_num_seqs, max_model_len, buckets,
                     quantized, qdtype, qtype, not_converted, kwargs) -> None:
