@@ -307,7 +307,8 @@ int mi_op_quantize_weight(const float* w, int32_t N, int32_t K, int32_t weight_d
 int mi_op_untile_weight(const void* tiled, int32_t N, int32_t K, int32_t weight_dtype,
                         void* q_out, void* stream);
 /* y[M, N] fp32 = (x[M, K] bf16 . Wq^T) * scale (+ bias).  M <= 16: weight-streaming GEMV;
- * else MFMA GEMM.  force_path: 0 auto, 1 GEMV, 2 GEMM (picked by size), 3 the wide-N LDS-DMA GEMM (1-byte weights). */
+ * else MFMA GEMM.  force_path: 0 auto, 1 GEMV, 2 GEMM (picked by size), 3 the wide-N LDS-DMA GEMM (1-byte weights),
+ * 4 / 5 that GEMM with K split over 2 / 4 slices at 128-token blocks, 6 / 7 at 256-token blocks (K / 64 a multiple of the slices). */
 int mi_op_qlinear(const void* x_bf16, int32_t M, const void* w_tiled, const float* scale,
                   const float* bias, int32_t N, int32_t K, int32_t weight_dtype, float* y,
                   int32_t force_path, void* stream);

@@ -64,15 +64,18 @@ def test_quantize_bit_exact(lib, wd, qt):
 
 @pytest.mark.parametrize("wd", ["f8e4m3", "int8", "bf16"])
 @pytest.mark.parametrize("M,path", [(1, 1), (4, 1), (16, 1), (17, 1), (24, 1), (32, 1), (4, 2), (17, 2), (200, 2), (256, 2),
-                                    (17, 3), (200, 3), (300, 3)])     # 3 = the wide-N LDS-DMA GEMM; (17 .. 32, 1): two 16-column groups per weight stream
+                                    (17, 3), (200, 3), (300, 3),      # 3 = the wide-N LDS-DMA GEMM; (17 .. 32, 1): two 16-column groups per weight stream
+                                    (200, 4), (300, 5), (300, 6), (520, 7)])   # 4 .. 7 = the wide GEMM with K split over 2 / 4 slices (128- / 256-token blocks)
 @pytest.mark.parametrize("N,K", [(576, 448), (1024, 4096), (256, 14336), (3584, 18944), (272, 28672)])
 def test_qlinear(lib, wd, M, path, N, K):
     """(16, 14336), (4 / 16, 18944) and (* , 28672) on the GEMV path do not fit in LDS whole: they
     run the K-streamed weight-streaming kernel (gemv_kstream_kernel; Qwen2.5-7B / Llama-3.3-70B down_proj shapes)."""
     if K > 16384 and (path >= 2 or wd == "bf16") and M not in (4, 17, 32):
         pytest.skip("big-K shapes: one GEMM and one bf16 case are enough")
-    if path == 3 and wd == "bf16":
+    if path >= 3 and wd == "bf16":
         pytest.skip("the wide-N GEMM takes 1-byte weights")
+    if path >= 4 and (K // 64) % (4 if path & 1 else 2) != 0:
+        pytest.skip("K / 64 is not a multiple of the slices")
     torch.manual_seed(1)
     w = torch.randn(N, K) * 0.05
     x = torch.randn(M, K).to(torch.bfloat16)

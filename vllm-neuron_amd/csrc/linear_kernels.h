@@ -63,7 +63,9 @@ int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, co
                 hipStream_t s, float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0, SlabSum* defer = nullptr);
 int launch_splitk_flush(const SlabSum& sl, const float* resid_in, float* out, int ld_out, hipStream_t s);
 // the wide-N LDS-DMA variant of launch_gemm (1-byte weights); launch_gemm picks it by size
-int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s);
+int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                     float* splitk_ws = nullptr, size_t splitk_ws_bytes = 0, SlabSum* defer = nullptr, int force_bm = 0,
+                     int force_ks = 0);   // force_*: tests (token block 128 / 256, K slices)
 // M > 16 with FP8 activations: x8 = K-step-major e4m3 image [K / 128][ldx >= T rows][128 B] as
 // launch_rowquant_fp8 writes it (per-token scale in EpiArgs::row_scale), FP8 weights,
 // MX-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) at twice the bf16 rate.

@@ -1725,9 +1725,11 @@ constexpr int kWideBN = 256, kWideWBytes = 16 * 1024, kWideStages = 3;
 
 // BM = 128: each wave 64 x 64 (64 accumulator registers).  BM = 256: each 128 x 64 (128 accumulator registers, 246 VGPRs
 // with the decoded fragments of one K-step).
-template <int WD, int EPI, int BM>
+// SPLIT: grid.z K-slices write raw fp32 accumulators to slab[z][m][n] (see gemm_a8_kernel); K / 64 is a multiple of grid.z.
+template <int WD, int EPI, int BM, bool SPLIT>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
-                                                        const uint16_t* __restrict__ x, int ldx, EpiArgs e) {
+                                                        const uint16_t* __restrict__ x, int ldx, EpiArgs e,
+                                                        float* __restrict__ slab) {
   static_assert(WD != MI_W_BF16, "1-byte weight tiles (64 k per tile)");
   static_assert(BM == 128 || BM == 256, "token block");
   // waves as 2 (tokens) x 4 (weight rows), each MT 16-token tiles x 4 16-row weight tiles.  (4 x 2 waves of 64 x 128 read
@@ -1748,18 +1750,19 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict_
   const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
   if (nblk >= ntiles) return;
   const int m0 = mblk * BM, ntb = nblk * (kWideBN / 16);
-  const int nks = K / 64;
+  const int nks = SPLIT ? K / 64 / (int)gridDim.z : K / 64;     // this slice's K-steps, from K-step ks0 on
+  const int ks0 = SPLIT ? (int)blockIdx.z * nks : 0;
 
   // this lane's DMA sources: wave w brings weight tiles 2w, 2w + 1 of the work-group's 16 (fragment
   // order) and XP 8-row pieces of the activation tile
   const uint4* wsrc[2];
   const uint16_t* xsrc[XP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) wsrc[i] = W + (size_t)min(ntb + 2 * wave + i, NT - 1) * KT * 64 + lane;
+  for (int i = 0; i < 2; ++i) wsrc[i] = W + ((size_t)min(ntb + 2 * wave + i, NT - 1) * KT + ks0) * 64 + lane;
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int r = (XP * wave + i) * 8 + (lane >> 3), sl = lane & 7;
-    xsrc[i] = x + (size_t)min(m0 + r, T - 1) * ldx + ((sl ^ xs_swz<WD>(r)) * 8);   // LDS slot sl of row r holds chunk sl ^ swz(r)
+    xsrc[i] = x + (size_t)min(m0 + r, T - 1) * ldx + (size_t)ks0 * 64 + ((sl ^ xs_swz<WD>(r)) * 8);   // LDS slot sl of row r holds chunk sl ^ swz(r)
   }
   auto issue = [&](int ks) {
     unsigned char* st = smem + (ks % kWideStages) * kStage;
@@ -1846,30 +1849,35 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const uint4* __restrict_
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + wm * (BM / 2) + mt * 16 + c;
       if (m >= T) continue;
-      epilogue<EPI>(e, m, nt * 16 + g * 4, acc[i][mt]);
+      if constexpr (SPLIT) {
+        *reinterpret_cast<float4*>(slab + ((size_t)blockIdx.z * T + m) * (NT * 16) + nt * 16 + g * 4) =
+            make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+      } else {
+        epilogue<EPI>(e, m, nt * 16 + g * 4, acc[i][mt]);
+      }
     }
   }
 }
 
-static int gemm_wide_mode() {   // MI355X_GEMM_WIDE: 0 never, 1 whenever the shape allows, unset: by size
-  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE"); return v ? atoi(v) : -1; }();
-  return m;
-}
-static int gemm_wide_bm() {      // MI355X_GEMM_WIDE_BM: 128 / 256 forces the token block (default: by grid size)
-  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE_BM"); return v ? atoi(v) : 0; }();
-  return m;
-}
 template <int WD, int BM>
-static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                               int KS, float* splitk_ws, SlabSum* defer) {
   const int NT = w.N / 16, KT = w.K / 64;
   const int mtiles = ceil_div(T, BM), ntiles = ceil_div(w.N, kWideBN);
-  dim3 grid(8 * mtiles * ceil_div(ntiles, 8));
+  dim3 grid(8 * mtiles * ceil_div(ntiles, 8), 1, KS);
   const uint4* W = reinterpret_cast<const uint4*>(w.w);
   constexpr int lds = kWideStages * (kWideWBytes + BM * 128);
 #define MI_GW(EPI_) \
   do { \
-    MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_, BM>), lds)); \
-    hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_, BM>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e); \
+    if (KS == 1) { \
+      MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_, BM, false>), lds)); \
+      hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_, BM, false>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e, nullptr); \
+    } else { \
+      MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_kernel<WD, EPI_, BM, true>), lds)); \
+      hipLaunchKernelGGL((gemm_wide_kernel<WD, EPI_, BM, true>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x, ldx, e, splitk_ws); \
+      if (defer && EPI_ == EPI_RESID) { *defer = SlabSum{splitk_ws, KS, T, w.N, e.scale, e.bias, e.row_scale}; } \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+    } \
   } while (0)
   if (epi == EPI_QKV) MI_GW(EPI_QKV);
   else if (epi == EPI_SWIGLU) MI_GW(EPI_SWIGLU);
@@ -1886,49 +1894,81 @@ static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int l
 //     gate|up 1024 tokens: 896 (3.5 rounds)                                 224.5 vs 227.6      QKV 1024: 192 (one round, 75 %) 66.6 vs 84.2
 //     QKV  512: 96 work-groups   64.6 vs 40.1      O / down 1024: 128   57.1 vs 40.7 / 166.6 vs 116.2 (K-split on the other side)
 //     QKV 2048: 384 (1.5 rounds, 75 %)  134.5 vs 112.4;  gate|up 2048: 403.6 at 128 tokens (7 rounds), 373.4 at 256 (3.5)
-// -> a block size is eligible with one partial round from 70 % of the CUs on or several rounds at 80 % fill; the cheaper eligible one runs.
-struct WidePlan { int bm; };   // 0: not wanted
-static WidePlan gemm_wide_plan(int T, int N) {
+// -> a shape is eligible with one partial round from 70 % of the CUs on or several rounds at 80 % fill; the cheapest eligible
+// (token block, K-split) runs: rounds x K-steps x time per K-step, plus, for a K-split, the slabs written and read once more
+// (~4 bytes/ns) and the launch that sums them.
+struct WidePlan { int bm, ks; };   // bm 0: not wanted
+static WidePlan gemm_wide_plan(int T, int N, int K, size_t ws_bytes) {
   int cus = 256;
   if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
-  WidePlan best{0};
-  int best_cost = 0;
+  const int nks = K / 64;
+  WidePlan best{0, 1};
+  double best_cost = 0.;
   for (int bm = 128; bm <= 256; bm *= 2) {
-    const int wgs = ceil_div(T, bm) * ceil_div(N, kWideBN), rounds = ceil_div(wgs, cus);
-    const bool ok = wgs < cus ? wgs * 10 >= cus * 7 : wgs * 5 >= rounds * cus * 4;
-    const int cost = rounds * (bm == 128 ? 90 : 145);
-    if (ok && (best.bm == 0 || cost < best_cost)) { best.bm = bm; best_cost = cost; }
+    for (int ks = 1; ks <= 8; ks *= 2) {
+      if (nks % ks != 0 || nks / ks < 8) continue;
+      if (ks > 1 && (size_t)ks * T * N * sizeof(float) > ws_bytes) continue;
+      const int wgs = ceil_div(T, bm) * ceil_div(N, kWideBN) * ks, rounds = ceil_div(wgs, cus);
+      const bool ok = wgs < cus ? wgs * 10 >= cus * 7 : wgs * 5 >= rounds * cus * 4;
+      if (!ok) continue;
+      double cost = (double)rounds * (nks / ks) * (bm == 128 ? 0.90 : 1.45);
+      if (ks > 1) cost += 4.0 + (double)(ks + 1) * T * N * 4.0 / 4.0e6 * 1.0;   // slabs out and in, the sum out
+      if (best.bm == 0 || cost < best_cost) { best = WidePlan{bm, ks}; best_cost = cost; }
+    }
   }
   return best;
 }
+static int gemm_wide_mode() {   // MI355X_GEMM_WIDE: 0 never, 1 whenever the shape allows, unset: by size
+  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE"); return v ? atoi(v) : -1; }();
+  return m;
+}
+static int gemm_wide_bm() {      // MI355X_GEMM_WIDE_BM: 128 / 256 forces the token block (default: by grid size)
+  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE_BM"); return v ? atoi(v) : 0; }();
+  return m;
+}
+static int gemm_wide_ks() {      // MI355X_GEMM_WIDE_KS: 1 = never split K in the wide kernel
+  static const int m = [] { const char* v = getenv("MI355X_GEMM_WIDE_KS"); return v ? atoi(v) : 0; }();
+  return m;
+}
 template <int WD>
-static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
-  int bm = gemm_wide_bm();
-  if (bm != 128 && bm != 256) bm = gemm_wide_plan(T, w.N).bm;
-  if (bm == 0) bm = ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512 ? 256 : 128;   // forced onto a shape the plan would not take
-  if (bm == 256) return launch_gemm_wide_bm<WD, 256>(w, T, x, ldx, epi, e, s);
-  return launch_gemm_wide_bm<WD, 128>(w, T, x, ldx, epi, e, s);
+static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                               float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer, int force_bm, int force_ks) {
+  WidePlan pl = gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 || !splitk_ws ? 0 : splitk_ws_bytes);
+  const int forced_bm = force_bm ? force_bm : gemm_wide_bm();
+  if (forced_bm == 128 || forced_bm == 256) pl = WidePlan{forced_bm, 1};
+  if (pl.bm == 0) pl = WidePlan{ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512 ? 256 : 128, 1};   // forced onto a shape the plan would not take
+  if (force_ks) {
+    MI_CHECK(force_ks >= 1 && (w.K / 64) % force_ks == 0 && (force_ks == 1 || (splitk_ws && (size_t)force_ks * T * w.N * 4 <= splitk_ws_bytes)),
+             "gemm_wide: forced K-split must divide K / 64 and fit the workspace");
+    pl.ks = force_ks;
+  }
+  if (pl.bm == 256) return launch_gemm_wide_bm<WD, 256>(w, T, x, ldx, epi, e, s, pl.ks, splitk_ws, defer);
+  return launch_gemm_wide_bm<WD, 128>(w, T, x, ldx, epi, e, s, pl.ks, splitk_ws, defer);
 }
 // the wide tile needs 1-byte weights
-static bool gemm_wide_wanted(const LinearW& w, int T, bool forced) {
+static bool gemm_wide_wanted(const LinearW& w, int T, size_t ws_bytes) {
   if (w.wd == MI_W_BF16 || w.K % 64 != 0 || (w.N / 16) < 2) return false;
   const int mode = gemm_wide_mode();
-  if (forced || mode == 1) return true;
+  if (mode == 1) return true;
   if (mode == 0) return false;
-  if (T < 256) return false;
-  return gemm_wide_plan(T, w.N).bm != 0;
+  if (T <= 128) return false;   // up to one 128-token block: the 128 x 128 kernel and its K-split (also the 33 .. 128-row decode batches)
+  return gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 ? 0 : ws_bytes).bm != 0;
 }
-int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s) {
+int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
+                     float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer, int force_bm, int force_ks) {
+  if (defer) *defer = SlabSum();
   MI_CHECK(w.wd != MI_W_BF16 && w.K % 64 == 0 && ldx % 8 == 0, "gemm_wide: 1-byte weights, K % 64 == 0");
-  if (w.wd == MI_W_F8E4M3) return launch_gemm_wide_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s);
-  return launch_gemm_wide_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s);
+  if (w.wd == MI_W_F8E4M3)
+    return launch_gemm_wide_wd<MI_W_F8E4M3>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer, force_bm, force_ks);
+  return launch_gemm_wide_wd<MI_W_INT8>(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer, force_bm, force_ks);
 }
 
 int launch_gemm(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
                 float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer) {
   if (defer) *defer = SlabSum();
   MI_CHECK(T >= 1, "gemm: T must be >= 1");
-  if (gemm_wide_wanted(w, T, false) && ldx % 8 == 0) return launch_gemm_wide(w, T, x, ldx, epi, e, s);
+  if (gemm_wide_wanted(w, T, splitk_ws ? splitk_ws_bytes : 0) && ldx % 8 == 0)
+    return launch_gemm_wide(w, T, x, ldx, epi, e, s, splitk_ws, splitk_ws_bytes, defer);
   MI_CHECK(w.N % 16 == 0 && w.K % 64 == 0, "gemm: N % 16 == 0 and K % 64 == 0 required");
   MI_CHECK(ldx % 8 == 0, "gemm: x row stride must be a multiple of 8 elements");
   switch (w.wd) {

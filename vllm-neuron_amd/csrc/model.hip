@@ -1762,6 +1762,16 @@ int mi_op_qlinear(const void* x, int32_t M, const void* w_tiled, const float* sc
   const bool gemv = force_path == 1 || (force_path == 0 && gemv_fits(M, K));
   if (gemv) return launch_gemv(W, M, PRO_BF16, p, EPI_F32, e, (hipStream_t)stream);
   if (force_path == 3) return launch_gemm_wide(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
+  if (force_path >= 4 && force_path <= 7) {   // the wide GEMM with its K dimension split: 4 / 5 = 2 / 4 slices at 128-token blocks, 6 / 7 at 256
+    const int ks = (force_path & 1) ? 4 : 2, bm = force_path >= 6 ? 256 : 128;
+    float* slab = nullptr;
+    const size_t bytes = (size_t)ks * M * N * 4;
+    MI_HIP(hipMalloc(reinterpret_cast<void**>(&slab), bytes));
+    int rc = launch_gemm_wide(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream, slab, bytes, nullptr, bm, ks);
+    hipStreamSynchronize((hipStream_t)stream);
+    hipFree(slab);
+    return rc;
+  }
   return launch_gemm(W, M, p.x, K, EPI_F32, e, (hipStream_t)stream);
 }
 int mi_op_qlinear_a8(const void* x, int32_t M, const void* w_tiled, const float* scale, const float* bias, int32_t N,
