@@ -150,6 +150,51 @@ def test_qlinear_fp8_activations(lib, M, N, K):
     assert err < tol, (err, tol)
 
 
+_A8_WIDE_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tests.test_ops_gpu import _a8_case
+from vllm_neuron_amd import _native as lib
+for M, N, K in [(200, 1024, 4096), (300, 576, 1024), (520, 256, 14336), (129, 272, 512)]:
+    err, tol = _a8_case(lib, M, N, K)
+    print("case", M, N, K, err, tol, flush=True)
+    assert err < tol, (M, N, K, err, tol)
+print("A8_WIDE_OK", flush=True)
+"""
+
+
+def _a8_case(lib, M, N, K):
+    torch.manual_seed(3)
+    w = torch.randn(N, K) * 0.05
+    x = (torch.randn(M, K) * torch.rand(M, 1) * 4).to(torch.bfloat16)
+    x[1] = 0
+    bias = torch.randn(N) * 0.1
+    tiled, scale = quantize_on_device(lib, w, "f8e4m3", "per_channel_symmetric")
+    wq = dequantize_weight(*quantize_weight(w, "f8e4m3", "per_channel_symmetric"))
+    xf = x.float()
+    amax = xf.abs().amax(1, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    xq = (xf / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+    ref = xq.double() @ wq.double().t() + bias.double()
+    y = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    xd, bd = dev(x), dev(bias)
+    lib.check(lib.load_library().mi_op_qlinear_a8(xd.data_ptr(), M, tiled.data_ptr(), scale.data_ptr(), bd.data_ptr(),
+                                                  N, K, y.data_ptr(), None))
+    torch.cuda.synchronize()
+    return (y.cpu().double() - ref).abs().max().item(), 2e-5 * ref.abs().max().item() + 1e-5 * (K ** 0.5)
+
+
+def test_qlinear_fp8_activations_on_the_wide_tile():
+    """gemm_a8_wide_kernel (128 x 256 x 128 LDS-DMA ring, wave groups half a K-step apart) is picked by grid size, which the
+    op-test shapes never reach: a child process forces it (MI355X_A8_WIDE=1 is read once per process).  Ragged token and
+    weight-row blocks, 4 .. 112 K-steps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355X_A8_WIDE="1")
+    r = subprocess.run([sys.executable, "-c", _A8_WIDE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "A8_WIDE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_rmsnorm(lib):
     torch.manual_seed(2)
     T, H = 37, 448

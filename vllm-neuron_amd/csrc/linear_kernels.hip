@@ -2114,6 +2114,129 @@ __global__ __launch_bounds__(256) void gemm_a8_kernel(const uint4* __restrict__ 
   MI_TRACE_END();
 }
 
+// ---- FP8 activations on the wide tile ------------------------------------------------------------
+// The kernel above keeps three work-groups of 128 x 128 on a CU and takes in 32 KiB per 4.2 MFLOP; this one is
+// gemm_wide_kernel's schedule (LDS-DMA ring of three stages, the two wave groups half a K-step apart) on 128 tokens x 256
+// weight rows x 128 K bytes: 16 + 32 KiB per 8.4 MFLOP, half the bytes per flop.  (256 x 256 would halve them again but is
+// 64 KiB a stage: two stages in 160 KiB, and two stages cannot carry the stagger -- profiles/r03_a8_wide_experiment.txt.)
+// A stage: [16 n-tiles][2 k-tiles][64 lanes x 16 B] weight fragments as stored, then 128 activation rows x 128 B with
+// 16-byte chunk ch of row r at slot ch ^ (r & 7) (the lane reads chunks g and 4 + g: conflict-free with that key).
+constexpr int kA8wStage = 32 * 1024 + 128 * 128, kA8wDma = 6;
+// (A ninth wave touching the lines of the K-step four ahead, to make the ring's DMAs L2 hits, cost 27 %: 260 -> 330 us on
+// gate|up at 2048 tokens -- profiles/r03_a8_wide_experiment.txt.)
+template <int EPI, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_a8_wide_kernel(const uint4* __restrict__ W, int NT, int KT, int T, int K,
+                                                           const uint8_t* __restrict__ x8, int ldx, EpiArgs e,
+                                                           float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, c = lane & 15;
+  const int wm = wave & 1, wn = wave >> 1;      // waves 2 (tokens) x 4 (weight rows), each 64 x 64
+  const int mtiles = ceil_div(T, 128), ntiles = ceil_div(NT, 16);
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mblk = seq % mtiles, nblk = (seq / mtiles) * 8 + xcd;
+  if (nblk >= ntiles) return;
+  const int m0 = mblk * 128, ntb = nblk * 16;
+  const int nks = SPLIT ? K / 128 / (int)gridDim.z : K / 128;
+  const int ks0 = SPLIT ? (int)blockIdx.z * nks : 0;
+  constexpr int kUnit = 0x7f7f7f7f;   // E8M0 block scales: 2^0
+
+  // DMA sources of this lane: weight n-tiles 2w, 2w + 1 (two k-tiles each, adjacent in the image), activation pieces 2w, 2w + 1
+  const uint4* wsrc[2];
+  const uint8_t* xsrc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) wsrc[i] = W + ((size_t)min(ntb + 2 * wave + i, NT - 1) * KT + 2 * ks0) * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (2 * wave + i) * 8 + (lane >> 3), sl = lane & 7;
+    xsrc[i] = x8 + ((size_t)ks0 * ldx + min(m0 + r, T - 1)) * 128 + ((sl ^ (r & 7)) * 16);
+  }
+  auto issue = [&](int ks) {
+    unsigned char* st = smem + (ks % kWideStages) * kA8wStage;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) glds16(wsrc[i] + ((size_t)ks * 2 + t) * 64, st + ((2 * wave + i) * 2 + t) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(xsrc[i] + (size_t)ks * ldx * 128, st + 32 * 1024 + (2 * wave + i) * 1024);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // the schedule of gemm_wide_kernel: READ (fragments to registers) / MULTIPLY (MFMAs only), the groups in opposite phases
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+  issue(0);
+  if (nks > 1) issue(1);
+  if (grp == 1) {
+    if (nks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kA8wDma) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  for (int ks = 0; ks < nks; ++ks) {
+    if (grp == 0) {
+      if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kA8wDma) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ks + 2 < nks) issue(ks + 2);
+    const unsigned char* st = smem + (ks % kWideStages) * kA8wStage;
+    const uint4* xs = reinterpret_cast<const uint4*>(st + 32 * 1024);
+    u32x4_t b0[4], b1[4], a0[4], a1[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r = wm * 64 + mt * 16 + c;
+      b0[mt] = *reinterpret_cast<const u32x4_t*>(&xs[r * 8 + (g ^ (r & 7))]);
+      b1[mt] = *reinterpret_cast<const u32x4_t*>(&xs[r * 8 + ((4 + g) ^ (r & 7))]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a0[i] = *reinterpret_cast<const u32x4_t*>(st + ((wn * 4 + i) * 2) * 1024 + lane * 16);
+      a1[i] = *reinterpret_cast<const u32x4_t*>(st + ((wn * 4 + i) * 2 + 1) * 1024 + lane * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(b0[j])); asm volatile("" : "+v"(b1[j]));
+      asm volatile("" : "+v"(a0[j])); asm volatile("" : "+v"(a1[j]));
+    }
+    if (grp == 1 && ks + 1 < nks) {
+      if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kA8wDma) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const i32x8_t b = {(int)b0[mt][0], (int)b0[mt][1], (int)b0[mt][2], (int)b0[mt][3], (int)b1[mt][0], (int)b1[mt][1], (int)b1[mt][2], (int)b1[mt][3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const i32x8_t a = {(int)a0[i][0], (int)a0[i][1], (int)a0[i][2], (int)a0[i][3], (int)a1[i][0], (int)a1[i][1], (int)a1[i][2], (int)a1[i][3]};
+        acc[i][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc[i][mt], 0, 0, 0, kUnit, 0, kUnit);
+      }
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nt = ntb + wn * 4 + i;
+    if (nt >= NT) continue;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wm * 64 + mt * 16 + c;
+      if (m >= T) continue;
+      if constexpr (SPLIT) {
+        *reinterpret_cast<float4*>(slab + ((size_t)blockIdx.z * T + m) * (NT * 16) + nt * 16 + g * 4) =
+            make_float4(acc[i][mt][0], acc[i][mt][1], acc[i][mt][2], acc[i][mt][3]);
+      } else {
+        epilogue<EPI>(e, m, nt * 16 + g * 4, acc[i][mt]);
+      }
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int KS, int T, int N, EpiArgs e) {
   const int q = blockIdx.x * 256 + threadIdx.x;      // one (m, 4 consecutive n) per thread
@@ -2150,6 +2273,56 @@ int launch_gemm_a8(const LinearW& w, int T, const uint8_t* x8, int ldx, int epi,
   MI_CHECK(gemm_a8_supported(w), "gemm_a8: needs fp8 weights, K % 128 == 0, N % 16 == 0");
   MI_CHECK(ldx >= T && e.row_scale != nullptr, "gemm_a8: x8 is the K-step-major image of >= T rows, with its row scales");
   const int NT = w.N / 16, KT = w.K / 64, nks = w.K / kA8BK;
+  {   // The wide tile (MI355X_A8_WIDE: 0 never, 1 always, unset: by plan) where its one-work-group-per-CU grid fills one or two
+      // rounds of the chip.  Measured on the Llama-8B shapes against the kernel below (us): 256 tokens gate|up 43.6 vs 45.9,
+      // down 24.0 vs 25.6, QKV 17.3 vs 19.4; 512: 76.9 vs 86.0, 34.8 vs 39.6, 23.5 vs 28.0; 1024: down 58.4 vs 68.2, QKV 48.8 vs
+      // 51.9 but gate|up (3.5 rounds) 145.0 vs 135.9; 2048: down 121.0 vs 136.1, O 46.2 vs 49.3, gate|up (7 rounds) 260.4 vs
+      // 254.2 -- on long grids the three resident work-groups of the 128 x 128 kernel hide more latency than the ring does.
+    static const int mode = [] { const char* v = getenv("MI355X_A8_WIDE"); return v ? atoi(v) : -1; }();
+    int cus = 256;
+    if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
+    int best_ks = 0;
+    double best_cost = 0.;
+    for (int ks = 1; ks <= 8; ks *= 2) {
+      if (nks % ks != 0 || nks / ks < 4) continue;
+      if (ks > 1 && (!splitk_ws || (size_t)ks * T * w.N * sizeof(float) > splitk_ws_bytes)) continue;
+      const int wgs = ceil_div(T, 128) * ceil_div(w.N, 256) * ks, rounds = ceil_div(wgs, cus);
+      const bool ok = mode == 1 || (rounds <= 2 && (wgs < cus ? wgs * 10 >= cus * 7 : wgs * 5 >= rounds * cus * 4));
+      if (!ok) continue;
+      double cost = (double)rounds * (nks / ks) * 1.0;
+      if (ks > 1) cost += 4.0 + (double)(ks + 1) * T * w.N * 4.0 / 4.0e6;
+      if (best_ks == 0 || cost < best_cost) { best_ks = ks; best_cost = cost; }
+    }
+    if (mode != 0 && best_ks && T > 128) {
+      const int KS = best_ks;
+      dim3 grid(8 * ceil_div(T, 128) * ceil_div(ceil_div(w.N, 256), 8), 1, KS);
+      const uint4* W = reinterpret_cast<const uint4*>(w.w);
+      constexpr int lds = kWideStages * kA8wStage;
+#define MI_A8W_L(EPI_, SPLIT_, WS_) \
+  do { \
+    MI_TRY_(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_a8_wide_kernel<EPI_, SPLIT_>), lds)); \
+    hipLaunchKernelGGL((gemm_a8_wide_kernel<EPI_, SPLIT_>), grid, dim3(512), lds, s, W, NT, KT, T, w.K, x8, ldx, e, WS_); \
+  } while (0)
+#define MI_A8W(EPI_) \
+  do { \
+    if (KS == 1) { \
+      MI_A8W_L(EPI_, false, nullptr); \
+    } else { \
+      MI_A8W_L(EPI_, true, splitk_ws); \
+      if (defer && EPI_ == EPI_RESID) { *defer = SlabSum{splitk_ws, KS, T, w.N, e.scale, e.bias, e.row_scale}; } \
+      else hipLaunchKernelGGL((splitk_reduce_kernel<EPI_>), dim3(ceil_div(T * (w.N / 4), 256)), dim3(256), 0, s, splitk_ws, KS, T, w.N, e); \
+    } \
+  } while (0)
+      if (epi == EPI_QKV) MI_A8W(EPI_QKV);
+      else if (epi == EPI_SWIGLU) MI_A8W(EPI_SWIGLU);
+      else if (epi == EPI_RESID) MI_A8W(EPI_RESID);
+      else MI_A8W(EPI_F32);
+#undef MI_A8W
+#undef MI_A8W_L
+      MI_HIP(hipGetLastError());
+      return MI_OK;
+    }
+  }
   // 128 x 128 tiles: 64 accumulator registers per lane leave room for three work-groups per CU,
   // which hide each other's load latency (the 256 x 128 tile ran one work-group per CU at 24 % of
   // the matrix-core rate: 29.7 ms for the 2048 bucket against 22.5 ms; forcing a fourth wave per
