@@ -524,7 +524,7 @@ def main():
         # HBM traffic per GEMV launch from the committed PMC pass of this same command (FETCH_SIZE,
         # gfx950-corrected; tools/pmc_summary.py) -- counters cannot be read from inside the process
         traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "r02_gemv_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r03_gemv_traffic.json")
         if args.model == "llama31_8b" and wd == "f8e4m3" and os.path.exists(tf):
             import hashlib
             with open(tf) as fh:
@@ -532,7 +532,7 @@ def main():
             traffic = doc["traffic_bytes_per_launch"]
             with open(os.path.join(ROOT, "vllm-neuron_amd", "csrc", "linear_kernels.hip"), "rb") as fh:
                 fresh = hashlib.sha1(fh.read()).hexdigest() == doc.get("kernel_source_sha1")
-            traffic_src = ("profiles/r02_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE pass of this command, x2 gfx950 "
+            traffic_src = ("profiles/r03_gemv_traffic.json (rocprofv3 --pmc FETCH_SIZE pass of this command, x2 gfx950 "
                            "correction: the counter tallies 128-B requests at 64 B)"
                            + ("" if fresh else " -- STALE: the GEMV source has changed since that pass"))
         roofline = {"bound": "hbm", "kernel": "mi::gemv_kernel / gemv_priv_kernel (all projections + lm_head of a step)",
