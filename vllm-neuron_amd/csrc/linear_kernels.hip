@@ -1898,7 +1898,7 @@ static int launch_gemm_wide_bm(const LinearW& w, int T, const uint16_t* x, int l
 // (token block, K-split) runs: rounds x K-steps x time per K-step, plus, for a K-split, the slabs written and read once more
 // (~4 bytes/ns) and the launch that sums them.
 struct WidePlan { int bm, ks; };   // bm 0: not wanted
-static WidePlan gemm_wide_plan(int T, int N, int K, size_t ws_bytes) {
+static WidePlan gemm_wide_plan(int T, int N, int K, size_t ws_bytes, int wd) {
   int cus = 256;
   if (device_num_cu(&cus) != MI_OK || cus < 1) cus = 256;
   const int nks = K / 64;
@@ -1911,8 +1911,15 @@ static WidePlan gemm_wide_plan(int T, int N, int K, size_t ws_bytes) {
       const int wgs = ceil_div(T, bm) * ceil_div(N, kWideBN) * ks, rounds = ceil_div(wgs, cus);
       const bool ok = wgs < cus ? wgs * 10 >= cus * 7 : wgs * 5 >= rounds * cus * 4;
       if (!ok) continue;
-      double cost = (double)rounds * (nks / ks) * (bm == 128 ? 0.90 : 1.45);
+      // INT8 codes cost the READ phase ~6 x the VALU work of the fp8 hardware convert: 1.38 / 1.73 us per K-step measured on
+      // the Qwen2.5-7B shapes (gate|up at 1024 tokens 387.8 us at 128-token blocks against 303.5 on the 128 x 128 kernel;
+      // at 2048 tokens 485 at 256-token blocks against 592) -- there the wide tile must also beat what the 128 x 128 kernel
+      // holds: 0.9 PF/s on grids that keep three work-groups per CU resident, 0.65 on its K-split grids
+      const bool i8 = wd == MI_W_INT8;
+      double cost = (double)rounds * (nks / ks) * (bm == 128 ? (i8 ? 1.38 : 0.90) : (i8 ? 1.73 : 1.45));
       if (ks > 1) cost += 4.0 + (double)(ks + 1) * T * N * 4.0 / 4.0e6 * 1.0;   // slabs out and in, the sum out
+      const double alt_pf = ceil_div(T, 128) * ceil_div(N, 128) >= 3 * cus ? 0.9e9 : 0.65e9;   // flops per us: full residency / a K-split grid
+      if (i8 && cost > 2.0 * T * N * (double)K / alt_pf) continue;
       if (best.bm == 0 || cost < best_cost) { best = WidePlan{bm, ks}; best_cost = cost; }
     }
   }
@@ -1933,7 +1940,7 @@ static int gemm_wide_ks() {      // MI355X_GEMM_WIDE_KS: 1 = never split K in th
 template <int WD>
 static int launch_gemm_wide_wd(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
                                float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer, int force_bm, int force_ks) {
-  WidePlan pl = gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 || !splitk_ws ? 0 : splitk_ws_bytes);
+  WidePlan pl = gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 || !splitk_ws ? 0 : splitk_ws_bytes, w.wd);
   const int forced_bm = force_bm ? force_bm : gemm_wide_bm();
   if (forced_bm == 128 || forced_bm == 256) pl = WidePlan{forced_bm, 1};
   if (pl.bm == 0) pl = WidePlan{ceil_div(T, 256) * ceil_div(w.N, kWideBN) >= 512 ? 256 : 128, 1};   // forced onto a shape the plan would not take
@@ -1952,7 +1959,7 @@ static bool gemm_wide_wanted(const LinearW& w, int T, size_t ws_bytes) {
   if (mode == 1) return true;
   if (mode == 0) return false;
   if (T <= 128) return false;   // up to one 128-token block: the 128 x 128 kernel and its K-split (also the 33 .. 128-row decode batches)
-  return gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 ? 0 : ws_bytes).bm != 0;
+  return gemm_wide_plan(T, w.N, w.K, gemm_wide_ks() == 1 ? 0 : ws_bytes, w.wd).bm != 0;
 }
 int launch_gemm_wide(const LinearW& w, int T, const uint16_t* x, int ldx, int epi, const EpiArgs& e, hipStream_t s,
                      float* splitk_ws, size_t splitk_ws_bytes, SlabSum* defer, int force_bm, int force_ks) {
