@@ -11,7 +11,7 @@ wd = sys.argv[1] if len(sys.argv) > 1 else "f8e4m3"
 ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 geo = QWEN25_7B if (len(sys.argv) > 4 and sys.argv[4] == "qwen") else LLAMA31_8B
-BS, MAXLEN, NSEQ, NB = 32, 2048, 4, 4097
+BS, MAXLEN, NSEQ, NB = 32, 2048, int(os.environ.get('ROWS', 4)), 4097   # ROWS=n: rows per step
 MB = MAXLEN // BS
 m = NativeModel(**geo, num_blocks=NB, block_size=BS, max_num_seqs=NSEQ, max_model_len=MAXLEN,
                 weight_dtype=MI_W[wd], quant_type=MI_Q["per_channel_symmetric"], quantize_lm_head=1,
@@ -21,7 +21,7 @@ m.init_synthetic_weights(1, 0.02)
 m.finalize()
 perm = (torch.randperm(NB - 1, generator=torch.Generator().manual_seed(2)) + 1).tolist()
 blocks = [perm[i * MB:(i + 1) * MB] for i in range(NSEQ)]
-inp = decode_inputs([1, 2, 3, 4], [ctx - 1] * NSEQ, blocks, BS, MAXLEN)
+inp = decode_inputs(list(range(1, NSEQ + 1)), [ctx - 1] * NSEQ, blocks, BS, MAXLEN)
 for _ in range(3):
     m.forward(**inp)
 m.replay_decode(20)
