@@ -514,122 +514,113 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
 }
 
 // ---- top-k / top-p rows: the vocabulary pre-selected by many work-groups ----------------------------
-// One work-group per row walks a 128k vocabulary twice and takes 87 us for four rows (top_k 50; 112 at top_k 256).  Measured
-// with this split: 20.8 us for the slices + 18 us for the candidates' pick = 38.6 us (44.9 at top_k 256); the slice kernel is
-// bound by its 32 one-barrier rounds, not by the 16 KiB it reads.  Here kSampleSplits work-groups
-// per row each hold a slice of the row in LDS, find the slice's top_k-th largest key there (the same 4-pass radix select)
-// and write the slice's top_k -- every logit above that key and, of the ones equal to it, the lowest-indexed -- in
-// ascending word order to the row's candidate array (kSampleMaxTopK slots per slice, the unused ones filled with a
-// negative NaN: its key is below -inf's, so it is never selected).  The row's top_k are among the slices' top_k, and an
-// equal-valued candidate the one-work-group rule would take is among its slice's: whatever ranks before it in the slice
-// ranks before it in the row.  sample_rows_kernel then runs on the candidates (idx_map) and picks the same word.
+// One work-group per row walks a 128k vocabulary twice and takes 87 us for four rows (top_k 50; 112 at top_k 256).  Here
+// kSampleSplits work-groups per row each take a slice of the row and write the slice's top_k -- every logit above the slice's
+// top_k-th largest key and, of the ones equal to it, the lowest-indexed -- in ascending word order to the row's candidate
+// array (kSampleMaxTopK slots per slice, the unused ones filled with a negative NaN: its key is below -inf's, so it is never
+// selected).  The row's top_k are among the slices' top_k, and an equal-valued candidate the one-work-group rule would take is
+// among its slice's: whatever ranks before it in the slice ranks before it in the row.  sample_rows_kernel then runs on the
+// candidates (idx_map) and picks the same word.  (First version: the slice in LDS, a bitwise bisection with one barrier per
+// round over four waves: 20.8 us; before that a 4-pass radix select in LDS whose 256-bin histogram collided on a handful of
+// exponent bins: 17-23 us.  This one, measured by early exits: loads 4.8 us, first stage 6.4 us, second stage 9.0 us = 20.1 us --
+// a round is 16 compare -> ballot -> scalar popcount chains, each paying the VALU -> SALU hand-off, x 32 rounds x 2 stages.)
 constexpr int kSampleSplits = 32;
-constexpr int kSliceMax = 8192;          // words of a slice held in LDS
+constexpr int kSliceMax = 8192;          // words of a slice (four waves x 32 registers x 64 lanes)
 constexpr int kSliceThreads = 256;
+
+// Wave-level selection, no LDS and no barrier: the wave holds up to KP x 64 elements in registers, element e = 64 i + lane of
+// its list (ascending word order in e), keys[i] its order key or 0 for "no element".  Writes the kk largest -- every key above
+// the kk-th largest and, of the equal ones, those with the lowest e -- to dst in ascending e; kk <= number of elements.
+// The threshold is found bit by bit from the top (t keeps a bit if at least kk keys are >= t with it set): a round is KP
+// compares + ballots + scalar popcounts.
+template <int KP, typename WordFn>
+__device__ __forceinline__ void wave_topk(const uint32_t (&keys)[KP], const float (&vals)[KP], WordFn word_of, int kk, float* dst_v,
+                                          int32_t* dst_i) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t t = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t c = t | (1u << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) cnt += (int)__popcll(__ballot(keys[i] >= c));
+    if (cnt >= kk) t = c;
+  }
+  int n_gt = 0;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) n_gt += (int)__popcll(__ballot(keys[i] > t));
+  const int need = kk - n_gt;             // of the elements AT the threshold: this many, lowest e first
+  int ties = 0, outp = 0;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const bool tie = keys[i] == t && keys[i] != 0u;
+    const unsigned long long tb = __ballot(tie);
+    const bool emit = keys[i] > t || (tie && ties + (int)__popcll(tb & below) < need);
+    const unsigned long long eb = __ballot(emit);
+    if (emit) {
+      const int pos = outp + (int)__popcll(eb & below);
+      dst_v[pos] = vals[i];
+      dst_i[pos] = word_of(i);
+    }
+    ties += (int)__popcll(tb);
+    outp += (int)__popcll(eb);
+  }
+}
+
+// One work-group per (slice, row): each of its four waves selects the top_k of a quarter of the slice on its own, wave 0 then
+// selects the slice's top_k from the four lists (<= 1024 candidates, still in ascending word order) and writes them.
+template <int KP>   // 64-element registers per lane and wave in the first stage: 16 up to a 131072-word vocabulary, else 32
 __global__ __launch_bounds__(kSliceThreads) void sample_slice_kernel(const float* __restrict__ logits, int T, int row_stride, int V_l,
                                                                      const float* __restrict__ params, float* __restrict__ cand_v,
                                                                      int32_t* __restrict__ cand_i) {
-  __shared__ float sv[kSliceMax + kSliceMax / 16];   // thread runs start 17 words apart per 16 (odd pitch: no bank conflicts walking runs)
-  __shared__ unsigned int scan_w[2][4];
+  __shared__ float s_v[4][kSampleMaxTopK];
+  __shared__ int32_t s_i[4][kSampleMaxTopK];
+  __shared__ int s_cnt[4];
   const int sp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int V = T * V_l, per = ceil_div(V, kSampleSplits);
-  const int v0 = min(sp * per, V), n = min(v0 + per, V) - v0;
+  const int V = T * V_l, per = ceil_div(V, kSampleSplits), sub = ceil_div(per, 4);
+  const int v1 = min(sp * per + per, V);
+  const int w0 = min(sp * per + wv * sub, v1), nw = min(w0 + sub, v1) - w0;   // this wave's words [w0, w0 + nw)
   int top_k = params ? (int)params[b * 3] : 1;
   top_k = min(max(top_k, 1), min(kSampleMaxTopK, V));
   float* out_v = cand_v + ((size_t)b * kSampleSplits + sp) * kSampleMaxTopK;
   int32_t* out_i = cand_i + ((size_t)b * kSampleSplits + sp) * kSampleMaxTopK;
   const float kFill = __builtin_bit_cast(float, 0xffc00000u);
-  const int k_loc = min(top_k, n);
-  // every load of the thread in flight at once;
-  // word j of the slice lives at sv[j + j / 16]
-  constexpr int kPer = kSliceMax / kSliceThreads;
-  uint32_t keys[kPer];
   {
-    float xv[kPer];
+    float vals[KP];
+    uint32_t keys[KP];
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int j = tid + i * kSliceThreads, v = v0 + j;
-      xv[i] = j >= n ? 0.f : T == 1 ? logits[(size_t)b * V_l + v] : logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)];
+    for (int i = 0; i < KP; ++i) {          // every load of the lane in flight at once
+      const int j = i * 64 + lane, v = w0 + j;
+      vals[i] = j >= nw ? 0.f : T == 1 ? logits[(size_t)b * V_l + v] : logits[((size_t)(v / V_l) * row_stride + b) * V_l + (v % V_l)];
     }
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int j = tid + i * kSliceThreads;
-      if (j < n) sv[j + (j >> 4)] = xv[i];
-      keys[i] = j < n ? f32_order_key(xv[i]) : 0u;   // key 0 is below every float's key but one NaN's: never counted for t >= 1
-    }
+    for (int i = 0; i < KP; ++i) keys[i] = i * 64 + lane < nw ? f32_order_key(vals[i]) : 0u;   // 0: below every float's key (but one NaN's)
+    const int kk = min(top_k, nw);
+    if (kk > 0) wave_topk<KP>(keys, vals, [&](int i) { return w0 + i * 64 + lane; }, kk, s_v[wv], s_i[wv]);
+    if (lane == 0) s_cnt[wv] = kk;
   }
   __syncthreads();
-  if (k_loc == 0) {   // an empty slice (V < kSampleSplits * per)
-    for (int j = tid; j < kSampleMaxTopK; j += kSliceThreads) { out_v[j] = kFill; out_i[j] = 0x7fffffff; }
-    return;
-  }
-  // The slice's k_loc-th largest key, bit by bit from the top: t keeps a bit if at least k_loc keys are >= t with that bit
-  // set.  A thread counts over its own keys in registers, a wave by a DPP sum, the four waves through two alternating LDS
-  // rows: 32 rounds of one barrier each, no atomics.
-  uint32_t t = 0;
-  unsigned int n_ge = (unsigned)n;          // keys >= t
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t c = t | (1u << bit);
-    unsigned int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) cnt += keys[i] >= c;
-    cnt = (unsigned)wave_sum((float)cnt);   // <= 64 * 32: exact in fp32
-    if (lane == 0) scan_w[bit & 1][wv] = cnt;
-    __syncthreads();
-    const unsigned int tot = scan_w[bit & 1][0] + scan_w[bit & 1][1] + scan_w[bit & 1][2] + scan_w[bit & 1][3];
-    if (tot >= (unsigned)k_loc) { t = c; n_ge = tot; }
-  }
-  // keys strictly above t: one more count
-  unsigned int n_gt;
+  if (wv != 0) return;
   {
-    unsigned int cnt = 0;
+    constexpr int KP2 = 4 * kSampleMaxTopK / 64;   // 16
+    float vals[KP2];
+    uint32_t keys[KP2];
+    int32_t words[KP2];
+    int total = 0;
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) cnt += keys[i] > t;
-    cnt = (unsigned)wave_sum((float)cnt);
-    __syncthreads();
-    if (lane == 0) scan_w[0][wv] = cnt;
-    __syncthreads();
-    n_gt = scan_w[0][0] + scan_w[0][1] + scan_w[0][2] + scan_w[0][3];
-    __syncthreads();
-  }
-  const uint32_t kth = t;
-  const unsigned int need = (unsigned)k_loc - n_gt;   // of the words AT the threshold: this many, lowest first
-  (void)n_ge;
-  // emission in ascending word order: thread t owns the run [t R, (t + 1) R); two scans over the threads give each run the
-  // number of threshold words before it and the output slot it starts at
-  const int R = ceil_div(n, kSliceThreads);
-  const int j0 = min(tid * R, n), j1 = min(j0 + R, n);
-  unsigned int my_gt = 0, my_tie = 0;
-  for (int j = j0; j < j1; ++j) {
-    const uint32_t key = f32_order_key(sv[j + (j >> 4)]);
-    my_gt += key > kth;
-    my_tie += key == kth;
-  }
-  auto block_exclusive = [&](unsigned int x, int slot) -> unsigned int {
-    unsigned int inc = x;
+    for (int w = 0; w < 4; ++w) total += s_cnt[w];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned int dn = __shfl_up(inc, off);
-      if (lane >= off) inc += dn;
+    for (int i = 0; i < KP2; ++i) {
+      const int e = i * 64 + lane, w = e / kSampleMaxTopK, j = e % kSampleMaxTopK;
+      const bool real = j < s_cnt[w];
+      vals[i] = real ? s_v[w][j] : 0.f;
+      words[i] = real ? s_i[w][j] : 0;
+      keys[i] = real ? f32_order_key(vals[i]) : 0u;
     }
-    if (lane == 63) scan_w[slot][wv] = inc;
-    __syncthreads();
-    unsigned int base = 0;
-    for (int w = 0; w < wv; ++w) base += scan_w[slot][w];
-    return base + inc - x;
-  };
-  const unsigned int tie0 = block_exclusive(my_tie, 0);
-  const unsigned int take = tie0 >= need ? 0u : min(my_tie, need - tie0);
-  unsigned int slot = block_exclusive(my_gt + take, 1);
-  unsigned int tie_rank = tie0;
-  for (int j = j0; j < j1; ++j) {
-    const float x = sv[j + (j >> 4)];
-    const uint32_t key = f32_order_key(x);
-    const bool emit = key > kth || (key == kth && tie_rank < need);
-    tie_rank += key == kth;
-    if (emit) { out_v[slot] = x; out_i[slot] = v0 + j; ++slot; }
+    const int kk = min(top_k, total);
+    if (kk > 0) wave_topk<KP2>(keys, vals, [&](int i) { return words[i]; }, kk, out_v, out_i);
+    for (int j = kk + lane; j < kSampleMaxTopK; j += 64) { out_v[j] = kFill; out_i[j] = 0x7fffffff; }
   }
-  for (int j = k_loc + tid; j < kSampleMaxTopK; j += kSliceThreads) { out_v[j] = kFill; out_i[j] = 0x7fffffff; }
 }
 
 // ---- all rows greedy: argmax split over the chip -------------------------------------------------
@@ -698,7 +689,10 @@ int launch_sample_rows(const float* logits, int T, int row_stride, int V_l, int 
     const int NC = kSampleSplits * kSampleMaxTopK;
     float* cv = reinterpret_cast<float*>(scratch);
     int32_t* ci = reinterpret_cast<int32_t*>(cv + (size_t)B * NC);
-    hipLaunchKernelGGL(sample_slice_kernel, dim3(kSampleSplits, B), dim3(kSliceThreads), 0, s, logits, T, row_stride, V_l, params, cv, ci);
+    if (ceil_div(ceil_div(V, kSampleSplits), 4) <= 16 * 64)
+      hipLaunchKernelGGL(sample_slice_kernel<16>, dim3(kSampleSplits, B), dim3(kSliceThreads), 0, s, logits, T, row_stride, V_l, params, cv, ci);
+    else
+      hipLaunchKernelGGL(sample_slice_kernel<32>, dim3(kSampleSplits, B), dim3(kSliceThreads), 0, s, logits, T, row_stride, V_l, params, cv, ci);
     hipLaunchKernelGGL(sample_rows_kernel, dim3(B), dim3(kSampleThreads), 0, s, cv, 1, B, NC, params, seed, row0, tokens, ci);
     MI_HIP(hipGetLastError());
     return MI_OK;
