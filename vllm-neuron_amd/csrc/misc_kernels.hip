@@ -522,40 +522,47 @@ __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
 // among its slice's: whatever ranks before it in the slice ranks before it in the row.  sample_rows_kernel then runs on the
 // candidates (idx_map) and picks the same word.  (First version: the slice in LDS, a bitwise bisection with one barrier per
 // round over four waves: 20.8 us; before that a 4-pass radix select in LDS whose 256-bin histogram collided on a handful of
-// exponent bins: 17-23 us.  This one, measured by early exits: loads 4.8 us, first stage 6.4 us, second stage 9.0 us = 20.1 us --
-// a round is 16 compare -> ballot -> scalar popcount chains, each paying the VALU -> SALU hand-off, x 32 rounds x 2 stages.)
+// exponent bins: 17-23 us.  This one with the full 32-round search, measured by early exits: loads 4.8 us, first stage 6.4 us,
+// second stage 9.0 us = 20.1 us -- a round is 16 compare -> ballot -> scalar popcount chains, each paying the VALU -> SALU
+// hand-off; with the search stopping once the candidates fit the slots: 11.8 us at top_k 50.)
 constexpr int kSampleSplits = 32;
 constexpr int kSliceMax = 8192;          // words of a slice (four waves x 32 registers x 64 lanes)
 constexpr int kSliceThreads = 256;
 
 // Wave-level selection, no LDS and no barrier: the wave holds up to KP x 64 elements in registers, element e = 64 i + lane of
-// its list (ascending word order in e), keys[i] its order key or 0 for "no element".  Writes the kk largest -- every key above
-// the kk-th largest and, of the equal ones, those with the lowest e -- to dst in ascending e; kk <= number of elements.
-// The threshold is found bit by bit from the top (t keeps a bit if at least kk keys are >= t with it set): a round is KP
-// compares + ballots + scalar popcounts.
+// its list (ascending word order in e), keys[i] its order key or 0 for "no element"; n elements in all.  Writes a SUPERSET of the
+// kk largest (kk <= n) of at most `cap` elements to dst in ascending e and returns its size.  The threshold is found bit by bit
+// from the top (t keeps a bit if at least kk keys are >= t with it set; a round is KP compares + ballots + scalar popcounts) and
+// the search stops as soon as no more than `cap` keys are >= t: all of those are written -- typically after a few rounds, the
+// exact selection being the business of whoever reads the list.  If the search runs to the last bit (more than cap keys >= the
+// kk-th largest: a mass of equal values), exactly kk are written: every key above the threshold and, of the equal ones, those
+// with the lowest e.
 template <int KP, typename WordFn>
-__device__ __forceinline__ void wave_topk(const uint32_t (&keys)[KP], const float (&vals)[KP], WordFn word_of, int kk, float* dst_v,
-                                          int32_t* dst_i) {
+__device__ __forceinline__ int wave_topk(const uint32_t (&keys)[KP], const float (&vals)[KP], WordFn word_of, int n, int kk, int cap,
+                                         float* dst_v, int32_t* dst_i) {
   const int lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t t = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+  int n_ge = n;                            // keys >= t (every element's key is >= 1 > 0)
+  for (int bit = 31; bit >= 0 && n_ge > cap; --bit) {
     const uint32_t c = t | (1u << bit);
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < KP; ++i) cnt += (int)__popcll(__ballot(keys[i] >= c));
-    if (cnt >= kk) t = c;
+    if (cnt >= kk) { t = c; n_ge = cnt; }
   }
   int n_gt = 0;
 #pragma unroll
   for (int i = 0; i < KP; ++i) n_gt += (int)__popcll(__ballot(keys[i] > t));
-  const int need = kk - n_gt;             // of the elements AT the threshold: this many, lowest e first
+  // everything >= t when that fits; else (all 32 bits fixed, t = the kk-th largest key) kk - n_gt of the elements AT t, lowest e first
+  const int need = n_ge <= cap ? n_ge - n_gt : kk - n_gt;
+  const uint32_t t_cmp = t == 0u ? 1u : t;   // t = 0: nothing was searched (n <= cap): every element (key >= 1) goes out via "above"
   int ties = 0, outp = 0;
 #pragma unroll
   for (int i = 0; i < KP; ++i) {
-    const bool tie = keys[i] == t && keys[i] != 0u;
+    const bool tie = keys[i] == t_cmp && t != 0u;
     const unsigned long long tb = __ballot(tie);
-    const bool emit = keys[i] > t || (tie && ties + (int)__popcll(tb & below) < need);
+    const bool emit = (t == 0u ? keys[i] != 0u : keys[i] > t) || (tie && ties + (int)__popcll(tb & below) < need);
     const unsigned long long eb = __ballot(emit);
     if (emit) {
       const int pos = outp + (int)__popcll(eb & below);
@@ -565,6 +572,7 @@ __device__ __forceinline__ void wave_topk(const uint32_t (&keys)[KP], const floa
     ties += (int)__popcll(tb);
     outp += (int)__popcll(eb);
   }
+  return outp;
 }
 
 // One work-group per (slice, row): each of its four waves selects the top_k of a quarter of the slice on its own, wave 0 then
@@ -596,8 +604,9 @@ __global__ __launch_bounds__(kSliceThreads) void sample_slice_kernel(const float
 #pragma unroll
     for (int i = 0; i < KP; ++i) keys[i] = i * 64 + lane < nw ? f32_order_key(vals[i]) : 0u;   // 0: below every float's key (but one NaN's)
     const int kk = min(top_k, nw);
-    if (kk > 0) wave_topk<KP>(keys, vals, [&](int i) { return w0 + i * 64 + lane; }, kk, s_v[wv], s_i[wv]);
-    if (lane == 0) s_cnt[wv] = kk;
+    int wrote = 0;
+    if (kk > 0) wrote = wave_topk<KP>(keys, vals, [&](int i) { return w0 + i * 64 + lane; }, nw, kk, kSampleMaxTopK, s_v[wv], s_i[wv]);
+    if (lane == 0) s_cnt[wv] = wrote;
   }
   __syncthreads();
   if (wv != 0) return;
@@ -618,8 +627,9 @@ __global__ __launch_bounds__(kSliceThreads) void sample_slice_kernel(const float
       keys[i] = real ? f32_order_key(vals[i]) : 0u;
     }
     const int kk = min(top_k, total);
-    if (kk > 0) wave_topk<KP2>(keys, vals, [&](int i) { return words[i]; }, kk, out_v, out_i);
-    for (int j = kk + lane; j < kSampleMaxTopK; j += 64) { out_v[j] = kFill; out_i[j] = 0x7fffffff; }
+    int wrote = 0;
+    if (kk > 0) wrote = wave_topk<KP2>(keys, vals, [&](int i) { return words[i]; }, total, kk, kSampleMaxTopK, out_v, out_i);
+    for (int j = wrote + lane; j < kSampleMaxTopK; j += 64) { out_v[j] = kFill; out_i[j] = 0x7fffffff; }
   }
 }
 
