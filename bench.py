@@ -349,6 +349,22 @@ def main():
                             tensor_parallel_size=tp, override_mi355x_config=o)
     t0 = time.perf_counter()
     eng = make_engine(False)                # the parity path: weight-only quantization everywhere
+    tp_note = None
+    if tp > 1 and not args.tp_loopback and args.tp_transport == "p2p":
+        # The peer-memory exchange has never run between two GPUs: if its first real steps fail -- the
+        # library's own self-test passed, or it would have switched to RCCL by itself -- say so and measure the RCCL transport
+        # instead of dying (flag waits are bounded: a broken exchange reports MI_ECOMM, it does not hang).
+        try:
+            eng.generate([list(range(1, 40))], SamplingParams(temperature=0.0, max_tokens=6))
+        except Exception as e:                                  # noqa: BLE001 -- whatever the transport throws
+            tp_note = f"p2p transport failed on its first steps ({type(e).__name__}: {str(e)[:200]}); RCCL transport measured instead"
+            print(f"[bench] {tp_note}", file=sys.stderr, flush=True)
+            try:
+                eng.worker.model_runner.model.model.close()
+            except Exception:                                   # noqa: BLE001
+                pass
+            override["tp_transport"] = "rccl"
+            eng = make_engine(False)
     native = eng.worker.model_runner.model.model
     init_s = time.perf_counter() - t0
 
@@ -611,6 +627,8 @@ def main():
             line["tp"] = native.tp_info()
         except Exception as ex:                                   # noqa: BLE001 -- the bench line must still be printed
             line["tp"] = {"error": str(ex)}
+        if tp_note:
+            line["tp"]["note"] = tp_note
     finish(line)
 
 
