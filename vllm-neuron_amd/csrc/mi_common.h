@@ -116,23 +116,13 @@ __device__ __forceinline__ uint4 nt_load16(const uint4* p) {
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// fp32 -> OCP e4m3fn, round-nearest-even, |f| <= 448 (software: bit-exact by construction)
+// fp32 -> OCP e4m3fn, round-nearest-even, saturating at +-448: the hardware convert of gfx950 (v_cvt_pk_fp8_f32; OCP
+// formats on this chip).  The clamp in front makes the result independent of the instruction's own out-of-range rule; a NaN
+// input becomes +-448 like any other out-of-range value.  (Until round 3 this was ~20 integer / select instructions per value:
+// the per-token quantization passes of the FP8-activation path were VALU-bound on it.)
 __device__ __forceinline__ uint32_t f32_to_e4m3fn(float f) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, f);
-  const uint32_t sign = (u >> 24) & 0x80u;
-  const float a = fabsf(f);
-  uint32_t code;
-  if (!(a < 448.f)) {
-    code = 0x7Eu;
-  } else if (a < 0.015625f) {            // below the smallest normal 2^-6: step 2^-9
-    code = (uint32_t)rintf(a * 512.f);    // 8 rounds up into the first normal, encoding is continuous
-  } else {
-    const uint32_t ub = u & 0x7fffffffu;
-    const uint32_t r = ub + 0x7FFFFu + ((ub >> 20) & 1u);
-    code = ((((r >> 23) - 127u + 7u) << 3) | ((r >> 20) & 7u));
-    code = code > 0x7Eu ? 0x7Eu : code;
-  }
-  return sign | code;
+  const float c = __builtin_fminf(__builtin_fmaxf(f, -448.f), 448.f);
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, 0.f, 0, false) & 0xffu;
 }
 
 
